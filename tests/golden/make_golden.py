@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by EXECUTING the reference's own gan_utils.py.
+
+Run in the build container only (needs /root/reference; the GPU box never sees it):
+
+    python tests/golden/make_golden.py [--ref /root/reference] [--only NAME ...]
+
+How: ``oracle/refshim`` (a NumPy stand-in for the ~20 ``tf.*`` primitives that
+file uses) is put first on sys.path, then ``gan_utils`` is imported from the
+reference directory *as it lies there* -- no reference source is copied.  Every
+number stored below is therefore produced by the reference's own control flow
+(positional eps/L quirk, Lmin = 100, u-then-v order, final sum(pi*C)); only the
+primitive array ops are NumPy's.  Each case is run twice: with ``tf.float32`` =
+float32 (the reference's arithmetic) and re-pointed at float64 (high-precision
+value of the same algorithm), the latter stored with an ``_f64`` suffix.
+
+Stored per case: the as-called loss, the three Sinkhorn costs and their
+executed iteration counts, the three modified cost matrices, the plain
+cost_xy matrix, compute_sinkhorn at several (epsilon, L) by keyword, the
+bi-causal cost and solve, benchmark_sinkhorn, pM, and an input checksum.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import cases  # noqa: E402
+
+
+def load_reference(ref_dir):
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "refshim"))
+    sys.path.insert(1, ref_dir)
+    import tensorflow as tf  # the stand-in
+    import gan_utils        # /root/reference/gan_utils.py, verbatim
+    assert os.path.realpath(gan_utils.__file__).startswith(os.path.realpath(ref_dir)), gan_utils.__file__
+    assert tf.__version__.endswith("numpy-standin")
+    return tf, gan_utils
+
+
+def flatten(v):
+    # same view the reference takes at gan_utils.py:217-220
+    v = np.transpose(v, (0, 2, 1, 3, 4))
+    return np.reshape(v, (v.shape[0], v.shape[1], -1))
+
+
+def counted(tf, fn, *a, **k):
+    before = tf.lse_calls
+    val = fn(*a, **k)
+    return val, (tf.lse_calls - before) // 2
+
+
+def run_case(tf, gu, shape, seed, regime, dtype, heavy):
+    sfx = "" if dtype == np.float32 else "_f64"
+    tf.set_float(dtype)
+    inp = cases.gen_inputs(shape, seed, regime)
+    real, fake = inp["real"].astype(dtype), inp["fake"].astype(dtype)
+    hf, mr, hr, mf = (inp[k].astype(dtype) for k in ("h_fake", "m_real", "h_real", "m_fake"))
+    sc = dtype(cases.SC)
+    out = {}
+    x, y = flatten(real), flatten(fake)
+
+    # the call kernel_train.py:247 makes (sinkhorn_eps=0.8, sinkhorn_l=100 are the CLI defaults)
+    loss, n3 = counted(tf, gu.compute_sinkhorn_loss, real, fake, sc, 0.8, 100, hf, mr, hr, mf, video=True)
+    out["loss"] = loss
+    out["loss_nits_total"] = n3
+    for tag, (a, b, h, m) in dict(xy=(x, y, hf, mr), xx=(x, x, hr, mr), yy=(y, y, hf, mf)).items():
+        val, n = counted(tf, gu.compute_sinkhorn, a, b, h, m, sc)
+        out["w_" + tag] = val
+        out["nits_" + tag] = n
+        out["C_" + tag] = gu.modified_cost(a, b, h, m, sc)
+    out["pM"] = gu.scale_invariante_martingale_regularization(mr, dtype(cases.LAM), sc)
+    if not heavy:
+        # quirk 1: a different (eps, L) request changes nothing
+        out["loss_eps0p1_L5"] = gu.compute_sinkhorn_loss(real, fake, sc, 0.1, 5, hf, mr, hr, mf, video=True)
+        out["C_plain"] = gu.cost_xy(x, y, sc)
+        for eps, L in cases.EPS_L:
+            val, n = counted(tf, gu.compute_sinkhorn, x, y, hf, mr, sc, epsilon=dtype(eps), L=L)
+            key = "e%g_L%d" % (eps, L)
+            out["w_" + key] = val
+            out["nits_" + key] = n
+        val, n = counted(tf, gu.compute_sinkhorn, x, y, hf, mr, sc, hx=hr, My=mf, bi_causal=True)
+        out["w_bicausal"], out["nits_bicausal"] = val, n
+        out["C_bicausal"] = gu.bi_causal_modified_cost(x, y, hf, mr, hr, mf, sc)
+        val, n = counted(tf, gu.benchmark_sinkhorn, x, y, sc)
+        out["w_bench_default"], out["nits_bench_default"] = val, n
+        val, n = counted(tf, gu.benchmark_sinkhorn, x, y, sc, epsilon=dtype(0.8), L=50, Lmin=20)
+        out["w_bench_e0.8_L50_Lmin20"], out["nits_bench_e0.8_L50_Lmin20"] = val, n
+        out["N_m_real"] = gu.compute_N(mr)
+    res = {k + sfx: np.asarray(v) for k, v in out.items()}
+    if dtype == np.float32:
+        res["checksum"] = cases.checksum(inp)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    tf, gu = load_reference(args.ref)
+    if not args.only or "line32" in args.only:
+        res = {}
+        for dtype in (np.float32, np.float64):
+            tf.set_float(dtype)
+            x, y, h, M = (a.astype(dtype) for a in cases.gen_line_inputs())
+            for sc, L in cases.LINE_RUNS:
+                val, n = counted(tf, gu.compute_sinkhorn, x, y, h, M, dtype(sc), L=L)
+                key = "sc%g_L%d%s" % (sc, L, "" if dtype == np.float32 else "_f64")
+                res["w_" + key], res["nits_" + key] = np.asarray(val), np.asarray(n)
+        tf.set_float(np.float32)
+        np.savez(os.path.join(HERE, "line32.npz"), **res)
+        print("line32", {k: (float(v) if k[0] == "w" else int(v)) for k, v in res.items()
+                         if not k.endswith("_f64")}, flush=True)
+    for shape, seed, regime in cases.CASES:
+        name = cases.case_name(shape, seed, regime)
+        if args.only and name not in args.only and shape not in args.only:
+            continue
+        heavy = shape == "cfg2"
+        t0 = time.time()
+        res = {}
+        for dtype in (np.float32, np.float64):
+            res.update(run_case(tf, gu, shape, seed, regime, dtype, heavy))
+        tf.set_float(np.float32)
+        for k, v in res.items():
+            if not k.endswith("_f64") and k != "checksum" and not k.startswith("nits") \
+                    and k != "loss_nits_total":
+                assert v.dtype == np.float32, (k, v.dtype)  # the reference path stayed in fp32
+        np.savez(os.path.join(HERE, name + ".npz"), **res)
+        print("%-20s loss=%.6f (f64 %.9f) nits=%s  %.1fs" % (
+            name, res["loss"], res["loss_f64"],
+            (int(res["nits_xy"]), int(res["nits_xx"]), int(res["nits_yy"])), time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    main()
