@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one step = one compute_sinkhorn_loss evaluation, forward + backward
+(gradients w.r.t. fake, h_fake, h_real, m_real, m_fake -- what the reference's generator step
+differentiates, kernel_train.py:287-289), on synthetic video already resident in HBM.
+
+Workload = BASELINE.json configs[1]: Moving-MNIST shape [B=64, H=64, T=30, W=64, C=1], J=8,
+scaling_coef=1/15, epsilon=1, 100 Sinkhorn iterations (the as-called behaviour of the
+reference: gan_utils.py:221-223).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `value` = loss evaluations per second over the whole job;
+`ms_per_step` = the BASELINE "Sinkhorn-loss ms/iter".  `roofline` describes the dominant
+kernel of cost assembly (the K-split partial-Gram kernel), timed live with stream events;
+`cpu_baseline` is the CPU oracle in the reference's own formulation timed on this box's host
+cores on a bounded sample (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+SHAPE = dict(B=64, H=64, T=30, W=64, C=1, J=8)
+SC = 1.0 / 15.0
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+
+
+def make_inputs(B, seed, device):
+    import cases
+    shape_name = "cfg2"
+    assert cases.SHAPES[shape_name][0] == SHAPE["B"]
+    inp = cases.gen_inputs(shape_name, seed, "near")
+    if B != SHAPE["B"]:
+        inp = {k: v[:B] for k, v in inp.items()}
+    return inp, {k: torch.from_numpy(v).to(device) for k, v in inp.items()}
+
+
+def loss_step(G, t):
+    loss = G.compute_sinkhorn_loss(t["real"], t["fake"], SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"],
+                                   t["m_fake"], video=True)
+    grads = torch.autograd.grad(loss, [t["fake"], t["h_fake"], t["h_real"], t["m_real"], t["m_fake"]])
+    return loss, grads
+
+
+def time_cost_kernel(t, reps=200):
+    """Average duration of the dominant cost kernel alone (KCCOT_COST_PARTIAL_ONLY), measured with
+    events on the stream the kernel is launched on (torch's current stream)."""
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, ptr, stream_of, workspace, check
+    B = t["real"].shape[0]
+    real, fake = t["real"].detach().reshape(B, -1), t["fake"].detach().reshape(B, -1)
+    K = real.shape[1]
+    T, J = t["h_fake"].shape[1], t["h_fake"].shape[2]
+    C3 = torch.empty(3, B, B, device=real.device)
+    ws, wsb = workspace(lib.kccot_pairwise_cost3_workspace_bytes(B, K), real)
+    hf, hr, mr, mf = (t[k].detach() for k in ("h_fake", "h_real", "m_real", "m_fake"))
+
+    def launch(flags):
+        check(lib.kccot_pairwise_cost3_f32(ptr(real), ptr(fake), B, K, SC, ptr(hf), ptr(hr), ptr(mr), ptr(mf),
+                                           T, J, flags, ptr(C3), ws, wsb, stream_of(real)), "pairwise_cost3")
+
+    out = {}
+    for name, flags in (("partial", _lib.COST_PARTIAL_ONLY), ("stage", 0)):
+        for _ in range(10):
+            launch(flags)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch(flags)
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / reps * 1e3   # us
+    return out, K
+
+
+def cpu_baseline(inp, budget_s=25.0):
+    """The CPU oracle in the reference's formulation ([B,B,T,D] broadcast, three separate cost
+    builds, eager per-iteration Sinkhorn ops, autograd through the unrolled loop), fp32, all host
+    threads torch uses.  Bounded: at least one evaluation, then as many as fit in the budget."""
+    from oracle import gan_utils_torch as ot
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
+        t[k].requires_grad_(True)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        loss = ot.compute_sinkhorn_loss(t["real"], t["fake"], SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"],
+                                        t["m_fake"], video=True)
+        torch.autograd.grad(loss, [t["fake"], t["h_fake"], t["h_real"], t["m_real"], t["m_fake"]])
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or el + el / n > 1.6 * budget_s:
+            break
+    return dict(value=n / el, unit="loss-evals/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d fwd+bwd evaluations of configs[1] (B=64,T=30,64x64x1, reference formulation, torch-CPU fp32) "
+                       "in %.1f s; host has %d logical cpus" % (n, el, os.cpu_count()),
+                loss=float(loss))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)"
+                             % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from kccotgan_amd import gan_utils as G
+    inp, t = make_inputs(SHAPE["B"], 0, dev)
+    for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
+        t[k].requires_grad_(True)
+
+    if world > 1:
+        from kccotgan_amd import dist as kd
+        shard = kd.shard_batch(t, rank, world)
+        step = lambda: kd.sharded_loss_step(shard, SC, rank, world)
+    else:
+        step = lambda: loss_step(G, t)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, _g = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _g = step()
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt)
+    ms = el / args.steps * 1e3
+    nits = G.last_info["compute_sinkhorn_loss"].tolist()
+
+    out = {
+        "metric": "sinkhorn_loss_evals_per_sec", "value": args.steps / el, "unit": "loss-evals/s (fwd+bwd)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: Moving-MNIST shape B=64,T=30,64x64x1, J=8, 100 Sinkhorn iters, "
+                               "compute_sinkhorn_loss fwd+bwd", "global_batch": SHAPE["B"],
+                   "parallelism": "single GPU" if world == 1 else "batch-sharded x%d, all-gather, replicated Sinkhorn" % world,
+                   "sinkhorn_iters_executed": nits, "loss": float(loss)},
+    }
+    if rank == 0 and world == 1:
+        kt, K = time_cost_kernel(t)
+        B, T, J = SHAPE["B"], SHAPE["T"], SHAPE["J"]
+        alg_bytes = 2 * B * K * 4 + 16 * B * T * J + 12 * B * B            # read real+fake once
+        alg_flops = 4 * B * B * K                                          # xy full + xx, yy triangles (8(d))
+        exec_flops = 10 * 2 * 32 * 32 * K                                  # ten 32x32 Gram sub-tiles on the MFMA pipe
+        t_s = kt["partial"] * 1e-6
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("gram128_partial_bytes_per_launch")
+        out["roofline"] = {
+            "kernel": "gram128_partial", "bound": "mfma", "achieved": alg_flops / t_s / 1e12,
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flops / t_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "traffic": traffic, "kernel_us": kt["partial"], "cost_stage_us": kt["stage"],
+            "executed_mfma_tflops": exec_flops / t_s / 1e12,
+            "hbm_achieved_GBs": alg_bytes / t_s / 1e9, "hbm_frac": alg_bytes / t_s / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(inp)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

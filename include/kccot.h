@@ -1,0 +1,168 @@
+/*
+ * kccot.h -- C ABI of the MI355X-native causal-OT (Sinkhorn) + kernel-smoothing loss path.
+ *
+ * This is the drop-in boundary for the hot path of neuripss2020/kccotgan.
+ * The reference has no FFI: its boundary is a set of Python call signatures in gan_utils.py /
+ * data_utils.py.  Every entry point below cites the reference function whose arithmetic it
+ * replaces; the Python host mirror (kccotgan_amd/gan_utils.py, kccotgan_amd/data_utils.py)
+ * keeps those signatures and binds these symbols through ctypes.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) unless named host_*; fp32, row-major, contiguous;
+ *     video tensors are viewed as [B, K] with K = T*H*W*C (the reference's
+ *     transpose(0,2,1,3,4) at gan_utils.py:217-220 does not change a sum over all of T,H,W,C,
+ *     so the native [B,H,T,W,C] buffer is read as-is);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); nothing allocates, frees or synchronises: the caller owns outputs and the
+ *     workspace (size from the matching *_workspace_bytes query);
+ *   - inputs are never written; NaN/Inf propagate unchanged (the caller's np.isfinite guard,
+ *     kernel_train.py:323, keeps working);
+ *   - return value: 0 = ok; KCCOT_E* < 0 = rejected before any launch; > 0 = a hipError_t
+ *     from the launch.  kccot_last_error() returns a thread-local message.
+ */
+#ifndef KCCOT_H
+#define KCCOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KCCOT_VERSION 100          /* 0.1.0 */
+#define KCCOT_EINVAL (-1)          /* bad shape / null pointer / inconsistent arguments      */
+#define KCCOT_EUNSUPPORTED (-2)    /* valid request outside what this build implements       */
+#define KCCOT_EWORKSPACE (-3)      /* workspace too small                                    */
+
+/* cost flags */
+#define KCCOT_COST_SAME 1u         /* x and y are the same tensor: upper triangle computed,   */
+                                   /* mirrored, l2 diagonal exactly 0 (as gan_utils.py:16)    */
+#define KCCOT_COST_FORCE_DIRECT 2u /* use the direct-difference kernel (exact (x-y)^2 form)   */
+#define KCCOT_COST_FORCE_MFMA 4u   /* use the stacked-Gram f32-MFMA kernel                    */
+#define KCCOT_COST_PARTIAL_ONLY 8u /* profiling aid: launch only the K-split partial kernel   */
+                                   /* (the dominant one); C_out is NOT written                */
+
+/* Sinkhorn stop modes */
+#define KCCOT_STOP_COUNT 0         /* compute_sinkhorn: stop when err<thresh && nits >= Lmin  */
+                                   /*   (gan_utils.py:157-160)                                */
+#define KCCOT_STOP_INDEX 1         /* benchmark_sinkhorn: ... && loop index i >= Lmin (:116)  */
+
+typedef void* kccot_stream_t;
+
+int kccot_version(void);
+const char* kccot_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pairwise cost.  Replaces cost_xy (gan_utils.py:6-18), modified_cost (:21-43) and
+ * bi_causal_modified_cost (:46-72):
+ *     C[i,j] = sc * sum_k (x[i,k]-y[j,k])^2
+ *            + sc * sum_{t<T-1,q} h1[i,t,q] * (M1[j,t+1,q]-M1[j,t,q])      if h1 != NULL
+ *            + sc * sum_{t<T-1,q} h2[i,t,q] * (M2[j,t+1,q]-M2[j,t,q])      if h2 != NULL
+ * h* index ROWS ([Bx,T,J]), M* index COLUMNS ([By,T,J]) -- gan_utils.py:37.
+ * C_out is [Bx,By].
+ * ------------------------------------------------------------------------------------------- */
+size_t kccot_pairwise_cost_workspace_bytes(int Bx, int By, int64_t K);
+int kccot_pairwise_cost_f32(const float* x, const float* y, int Bx, int By, int64_t K, float sc,
+                            const float* h1, const float* M1, const float* h2, const float* M2,
+                            int T, int J, unsigned flags, float* C_out,
+                            void* ws, size_t ws_bytes, kccot_stream_t stream);
+
+/* The three cost matrices of compute_sinkhorn_loss (gan_utils.py:221-223) in one pass that
+ * reads `real` and `fake` once:  C3[0] = xy: modified_cost(real, fake, h_fake, m_real)
+ *                                C3[1] = xx: modified_cost(real, real, h_real, m_real)
+ *                                C3[2] = yy: modified_cost(fake, fake, h_fake, m_fake)
+ * C3 is [3,B,B]. */
+size_t kccot_pairwise_cost3_workspace_bytes(int B, int64_t K);
+int kccot_pairwise_cost3_f32(const float* real, const float* fake, int B, int64_t K, float sc,
+                             const float* h_fake, const float* h_real,
+                             const float* m_real, const float* m_fake, int T, int J,
+                             unsigned flags, float* C3,
+                             void* ws, size_t ws_bytes, kccot_stream_t stream);
+
+/* Backward of the three cost matrices: given g3 = dLoss/dC3 [3,B,B] writes
+ *   dfake [B,K] (may be NULL), dh_fake, dh_real, dm_real, dm_fake [B,T,J] (each may be NULL).
+ * real never receives a gradient (kernel_train.py:252,289). */
+size_t kccot_pairwise_cost3_bwd_workspace_bytes(int B, int64_t K);
+int kccot_pairwise_cost3_bwd_f32(const float* g3, const float* real, const float* fake, int B,
+                                 int64_t K, float sc, const float* h_fake, const float* h_real,
+                                 const float* m_real, const float* m_fake, int T, int J,
+                                 float* dfake, float* dh_fake, float* dh_real, float* dm_real,
+                                 float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream);
+
+/* Backward of one general cost matrix (cost_xy / modified_cost): given g = dLoss/dC [Bx,By]
+ * writes dx [Bx,K], dy [By,K], dh [Bx,T,J], dM [By,T,J]; any of them may be NULL.  With
+ * KCCOT_COST_SAME (x is y) pass dy = NULL: dx receives both contributions. */
+size_t kccot_pairwise_cost_bwd_workspace_bytes(int Bx, int By);
+int kccot_pairwise_cost_bwd_f32(const float* g, const float* x, const float* y, int Bx, int By,
+                                int64_t K, float sc, const float* h, const float* M, int T, int J,
+                                unsigned flags, float* dx, float* dy, float* dh, float* dM,
+                                void* ws, size_t ws_bytes, kccot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sinkhorn.  Replaces the loop and final cost of compute_sinkhorn (gan_utils.py:138-165) and
+ * benchmark_sinkhorn (:87-121) for `nprob` independent n x n problems (one workgroup each):
+ *   u = v = 0; repeat up to L times:
+ *     u += eps*(log(1/n) - LSE_j((-C+u+v^T)/eps));  v += eps*(log(1/n) - LSE_i((-C+u+v^T)/eps))
+ *     err = sum|u - u_prev|; stop per stop_mode once err < thresh
+ *   cost = sum(exp((-C+u+v^T)/eps) * C)
+ * C is [nprob,n,n].  cost_out [nprob], nits_out [nprob] (executed iterations, device int32).
+ * u_hist / v_hist [nprob,L,n] receive u and v after every executed iteration (needed by the
+ * backward; pass NULL for a forward-only evaluation).  pi_out [nprob,n,n] optional.
+ * ------------------------------------------------------------------------------------------- */
+size_t kccot_sinkhorn_workspace_bytes(int nprob, int n);
+int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float eps, int L, int Lmin,
+                           float thresh, int stop_mode, float* u_hist, float* v_hist,
+                           float* cost_out, int32_t* nits_out, float* pi_out,
+                           void* ws, size_t ws_bytes, kccot_stream_t stream);
+
+/* Reverse sweep through the executed iterations (what tf.GradientTape does through the unrolled
+ * loop, kernel_train.py:221,252,262,289): dC_out[p] = gcost[p] * dcost[p]/dC[p].  gcost is a
+ * DEVICE array [nprob]; nits is the device array written by the forward. */
+int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const float* v_hist,
+                           const int32_t* nits, int nprob, int n, float eps, int L,
+                           const float* gcost, float* dC_out,
+                           void* ws, size_t ws_bytes, kccot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Martingale penalty.  Replaces scale_invariante_martingale_regularization (gan_utils.py:179-201):
+ *   pM = lam * sc * sum_{t<T-1,q} | (1/B) sum_b (M[b,t+1,q]-M[b,t,q]) / (std_{b,t}(M[:,:,q]) + 1e-6) |
+ * (population std).  pm_out is one device float.  Backward: dM = gpm * dpM/dM with gpm a device
+ * float. */
+int kccot_martingale_fwd_f32(const float* M, int B, int T, int J, float lam, float sc,
+                             float* pm_out, kccot_stream_t stream);
+int kccot_martingale_bwd_f32(const float* M, int B, int T, int J, float lam, float sc,
+                             const float* gpm, float* dM, kccot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel smoothing.  Replaces KernelSmoothing.temporal_convolution (data_utils.py:503-521,
+ * axes = KCCOT_SMOOTH_T) and gaussian_convolution3D (:552-582, axes = T|H|W) on the native
+ * [B,H,T,W,C] layout: normalised (2r+1)-tap Gaussian exp(-d^2/(2 sigma^2)) along each selected
+ * axis (the 7x7x7 kernel of data_utils.py:493-501 is the outer product of the 1-D one), REFLECT
+ * borders, then division by the maximum of the WHOLE smoothed tensor (data_utils.py:520,573,581).
+ *   out       [B,H,T,W,C]
+ *   max_inout one device float: written with the tensor maximum.  With
+ *             KCCOT_SMOOTH_EXTERNAL_MAX it is READ instead (the batch-sharded caller has
+ *             all-reduced(MAX) it across ranks) and `out` is divided by it.
+ *   KCCOT_SMOOTH_NO_DIVIDE leaves `out` un-normalised and only writes the local maximum
+ *             (first phase of the sharded protocol).
+ * Backward: din = d(out)/d(in)^T gout, including the arg-max path of the global maximum.
+ * ------------------------------------------------------------------------------------------- */
+#define KCCOT_SMOOTH_T 1u
+#define KCCOT_SMOOTH_H 2u
+#define KCCOT_SMOOTH_W 4u
+#define KCCOT_SMOOTH_NO_DIVIDE 16u
+#define KCCOT_SMOOTH_EXTERNAL_MAX 32u
+size_t kccot_smooth_workspace_bytes(int B, int H, int T, int W, int C);
+int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W, int C, float sigma,
+                         int radius, unsigned axes_flags, float* out, float* max_inout,
+                         void* ws, size_t ws_bytes, kccot_stream_t stream);
+int kccot_smooth_bwd_f32(const float* gout, const float* out, const float* max_in,
+                         int B, int H, int T, int W, int C, float sigma, int radius,
+                         unsigned axes_flags, float* din,
+                         void* ws, size_t ws_bytes, kccot_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KCCOT_H */

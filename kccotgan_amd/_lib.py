@@ -1,0 +1,116 @@
+"""ctypes binding of the C-ABI library ``csrc/libkccot.so`` (declared in ``include/kccot.h``).
+
+The HIP library is the product: there is NO CPU fallback anywhere in this package.  If the
+shared object is missing or a call is made without a GPU tensor the import / call fails loudly.
+PyTorch is used for device memory, streams and autograd plumbing only.
+"""
+import ctypes
+import os
+
+import torch  # must be imported first: the library then binds to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkccot.so")
+
+EINVAL, EUNSUPPORTED, EWORKSPACE = -1, -2, -3
+
+COST_SAME, COST_FORCE_DIRECT, COST_FORCE_MFMA, COST_PARTIAL_ONLY = 1, 2, 4, 8
+STOP_COUNT, STOP_INDEX = 0, 1
+SMOOTH_T, SMOOTH_H, SMOOTH_W, SMOOTH_NO_DIVIDE, SMOOTH_EXTERNAL_MAX = 1, 2, 4, 16, 32
+
+_c = ctypes
+_fp = _c.c_void_p      # device pointers travel as plain addresses
+_i, _i64, _f, _u, _sz = _c.c_int, _c.c_int64, _c.c_float, _c.c_uint, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/kccot.h one to one
+SIGNATURES = {
+    "kccot_version": (_i, []),
+    "kccot_last_error": (_c.c_char_p, []),
+    "kccot_pairwise_cost_workspace_bytes": (_sz, [_i, _i, _i64]),
+    "kccot_pairwise_cost_f32": (_i, [_fp, _fp, _i, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _u, _fp, _fp, _sz, _fp]),
+    "kccot_pairwise_cost3_workspace_bytes": (_sz, [_i, _i64]),
+    "kccot_pairwise_cost3_f32": (_i, [_fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _u, _fp, _fp, _sz, _fp]),
+    "kccot_pairwise_cost3_bwd_workspace_bytes": (_sz, [_i, _i64]),
+    "kccot_pairwise_cost3_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i,
+                                          _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_pairwise_cost_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "kccot_pairwise_cost_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i, _i64, _f, _fp, _fp, _i, _i, _u,
+                                         _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_sinkhorn_workspace_bytes": (_sz, [_i, _i]),
+    "kccot_sinkhorn_fwd_f32": (_i, [_fp, _i, _i, _f, _i, _i, _f, _i, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_sinkhorn_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _i, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_martingale_fwd_f32": (_i, [_fp, _i, _i, _i, _f, _f, _fp, _fp]),
+    "kccot_martingale_bwd_f32": (_i, [_fp, _i, _i, _i, _f, _f, _fp, _fp, _fp]),
+    "kccot_smooth_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "kccot_smooth_fwd_f32": (_i, [_fp, _i, _i, _i, _i, _i, _f, _i, _u, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_smooth_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _i, _u, _fp, _fp, _sz, _fp]),
+}
+
+
+class KccotError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "kccotgan_amd: %s is missing -- build it with `make -C kccotgan_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library out of step
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    msg = lib.kccot_last_error().decode("utf-8", "replace")
+    if rc == EINVAL:
+        raise ValueError("%s: %s" % (what, msg))
+    if rc == EUNSUPPORTED:
+        raise NotImplementedError("%s: %s" % (what, msg))
+    raise KccotError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise KccotError("kccotgan_amd needs tensors on a ROCm device (got %s); there is no CPU path" % t.device)
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL).  Refuses anything the kernels cannot read."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise KccotError("kccotgan_amd needs tensors on a ROCm device (got %s); there is no CPU path" % t.device)
+    if t.dtype != torch.float32 and t.dtype != torch.int32:
+        raise TypeError("kccotgan_amd kernels are fp32 (got %s)" % t.dtype)
+    if not t.is_contiguous():
+        raise ValueError("kccotgan_amd kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_of(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, ref):
+    """A per-(device, stream) scratch buffer, grown on demand.  Calls issued on one stream are
+    ordered, so successive kernels may reuse it."""
+    if nbytes <= 0:
+        return None, 0
+    key = (ref.device, stream_of(ref))
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=ref.device)
+        _ws_cache[key] = buf
+    return buf.data_ptr(), buf.numel()

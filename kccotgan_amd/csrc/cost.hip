@@ -1,0 +1,296 @@
+// Pairwise cost matrices of the causal-OT loss (replaces gan_utils.py:6-72 of the reference).
+//
+//   C[i,j] = sc * sum_k (x[i,k]-y[j,k])^2 + sc * sum_{t<T-1,q} h[i,t,q]*(M[j,t+1,q]-M[j,t,q])
+//
+// The contraction length K = T*H*W*C is 1e5..2e6 while the output is only B x B (B = 8..512), so
+// the work is split along K: every workgroup owns one 64x64 output tile over one K-chunk and
+// writes a partial tile; `cost_finalize` sums the chunks (fp64 accumulate, fixed order, so the
+// result is run-to-run deterministic), applies the scale, mirrors the lower triangle of x==y
+// problems and adds the causal term (a [(T-1)J]-long contraction, negligible work).
+//
+// Two partial-tile kernels:
+//   cost_direct_partial : VALU, exact direct-difference form (x-y)^2 as the reference computes
+//                         it (gan_utils.py:16).  Any shape.
+//   gram128_partial     : (cost_mfma.hip) stacked-Gram form on the f32 MFMA pipe, for operands
+//                         of at most 64 rows (the BASELINE configs[1] shape).
+#include "common.h"
+#include "cost_internal.h"
+
+namespace kccot {
+
+// ------------------------------------------------------------------------------------------
+// direct-difference partial tiles
+// block = 256 threads as 16 (ty) x 16 (tx); thread owns rows ty+16a, cols tx+16b (a,b < 4).
+// LDS tiles are [64][KT+4] floats: the +4 pitch makes the 16 rows a 16-lane ds_read_b128 group
+// touches land on 16 distinct 4-bank slots (36*r mod 64 is a permutation of multiples of 4).
+// ------------------------------------------------------------------------------------------
+constexpr int DT = 64;       // tile edge
+constexpr int DKT = 32;      // k-tile
+constexpr int DPITCH = DKT + 4;
+
+__device__ __forceinline__ float4 load4_guard(const float* __restrict__ row, int64_t k, int64_t kend,
+                                              bool rowok, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!rowok) return v;
+    if (vec && k + 4 <= kend) return *reinterpret_cast<const float4*>(row + k);
+    if (k + 0 < kend) v.x = row[k + 0];
+    if (k + 1 < kend) v.y = row[k + 1];
+    if (k + 2 < kend) v.z = row[k + 2];
+    if (k + 3 < kend) v.w = row[k + 3];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void cost_direct_partial(CostBatch cb, int64_t K, int64_t chunk,
+                                                           int vec_ok) {
+    __shared__ __attribute__((aligned(16))) float xs[DT * DPITCH];
+    __shared__ __attribute__((aligned(16))) float ys[DT * DPITCH];
+
+    // decode (problem, tile_i, tile_j) from blockIdx.y
+    int tile = blockIdx.y, p = 0;
+    for (; p < cb.nprob; ++p) {
+        int nt = cb.p[p].tiles_i * cb.p[p].tiles_j;
+        if (tile < nt) break;
+        tile -= nt;
+    }
+    if (p >= cb.nprob) return;
+    const CostProb& pr = cb.p[p];
+    const int ti = tile / pr.tiles_j, tj = tile % pr.tiles_j;
+    if (pr.same && tj < ti) return;  // mirrored by cost_finalize
+    const int i0 = ti * DT, j0 = tj * DT;
+    const int64_t kbeg = (int64_t)blockIdx.x * chunk;
+    const int64_t kend = (kbeg + chunk < K) ? kbeg + chunk : K;
+    if (kbeg >= kend) return;
+
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    // staging assignment: float4 slot q = t + 256*m  ->  row q/8, column group q%8
+    const int srow0 = t >> 3, sc4 = (t & 7) * 4;
+    const float* xr0 = pr.x + (int64_t)(i0 + srow0) * K;
+    const float* xr1 = pr.x + (int64_t)(i0 + srow0 + 32) * K;
+    const float* yr0 = pr.y + (int64_t)(j0 + srow0) * K;
+    const float* yr1 = pr.y + (int64_t)(j0 + srow0 + 32) * K;
+    const bool xok0 = i0 + srow0 < pr.Bx, xok1 = i0 + srow0 + 32 < pr.Bx;
+    const bool yok0 = j0 + srow0 < pr.By, yok1 = j0 + srow0 + 32 < pr.By;
+    const bool vec = vec_ok != 0;
+
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+
+    float4 nx0 = load4_guard(xr0, kbeg + sc4, kend, xok0, vec);
+    float4 nx1 = load4_guard(xr1, kbeg + sc4, kend, xok1, vec);
+    float4 ny0 = load4_guard(yr0, kbeg + sc4, kend, yok0, vec);
+    float4 ny1 = load4_guard(yr1, kbeg + sc4, kend, yok1, vec);
+
+    for (int64_t k0 = kbeg; k0 < kend; k0 += DKT) {
+        *reinterpret_cast<float4*>(&xs[srow0 * DPITCH + sc4]) = nx0;
+        *reinterpret_cast<float4*>(&xs[(srow0 + 32) * DPITCH + sc4]) = nx1;
+        *reinterpret_cast<float4*>(&ys[srow0 * DPITCH + sc4]) = ny0;
+        *reinterpret_cast<float4*>(&ys[(srow0 + 32) * DPITCH + sc4]) = ny1;
+        __syncthreads();
+        const int64_t kn = k0 + DKT;
+        if (kn < kend) {  // prefetch the next k-tile while this one is consumed
+            nx0 = load4_guard(xr0, kn + sc4, kend, xok0, vec);
+            nx1 = load4_guard(xr1, kn + sc4, kend, xok1, vec);
+            ny0 = load4_guard(yr0, kn + sc4, kend, yok0, vec);
+            ny1 = load4_guard(yr1, kn + sc4, kend, yok1, vec);
+        }
+#pragma unroll
+        for (int kk = 0; kk < DKT; kk += 4) {
+            float4 xv[4], yv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                xv[a] = *reinterpret_cast<const float4*>(&xs[(ty + 16 * a) * DPITCH + kk]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                yv[b] = *reinterpret_cast<const float4*>(&ys[(tx + 16 * b) * DPITCH + kk]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    float d;
+                    d = xv[a].x - yv[b].x; acc[a][b] = fmaf(d, d, acc[a][b]);
+                    d = xv[a].y - yv[b].y; acc[a][b] = fmaf(d, d, acc[a][b]);
+                    d = xv[a].z - yv[b].z; acc[a][b] = fmaf(d, d, acc[a][b]);
+                    d = xv[a].w - yv[b].w; acc[a][b] = fmaf(d, d, acc[a][b]);
+                }
+        }
+        __syncthreads();
+    }
+
+    float* part = pr.partial + (int64_t)blockIdx.x * pr.Bx * pr.By;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = i0 + ty + 16 * a;
+        if (i >= pr.Bx) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + tx + 16 * b;
+            if (j < pr.By) part[(int64_t)i * pr.By + j] = acc[a][b];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// finalize: one thread per output element
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cost_finalize(CostBatch cb, int nchunk, float sc, int T, int J) {
+    const int p = blockIdx.y;
+    const CostProb& pr = cb.p[p];
+    const int64_t n = (int64_t)pr.Bx * pr.By;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int i = (int)(e / pr.By), j = (int)(e % pr.By);
+    float l2;
+    if (pr.same && i == j) {
+        l2 = 0.f;  // (x-x)^2 summed is exactly 0 in the reference (gan_utils.py:16)
+    } else {
+        // x==y problems only computed tiles with tile_j >= tile_i
+        const bool mirror = pr.same && (j / pr.tile) < (i / pr.tile);
+        const int64_t off = mirror ? (int64_t)j * pr.By + i : (int64_t)i * pr.By + j;
+        double s = 0.0;
+        for (int c = 0; c < nchunk; ++c) s += (double)pr.partial[(int64_t)c * n + off];
+        l2 = (float)s * sc;
+    }
+    float c = l2;
+    if (pr.h1) c += causal_dot(pr.h1, pr.M1, i, j, T, J) * sc;
+    if (pr.h2) c += causal_dot(pr.h2, pr.M2, i, j, T, J) * sc;
+    pr.out[e] = c;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static CostPlan plan_direct(int nprob, const int* Bx, const int* By, const int* same, int64_t K) {
+    CostPlan pl{};
+    pl.use_mfma = false;
+    pl.tile = DT;
+    int64_t ntiles = 0;
+    for (int p = 0; p < nprob; ++p) {
+        const int ti = (Bx[p] + DT - 1) / DT, tj = (By[p] + DT - 1) / DT;
+        ntiles += same[p] ? (int64_t)ti * (ti + 1) / 2 : (int64_t)ti * tj;
+    }
+    const int64_t ksteps = (K + DKT - 1) / DKT;
+    // ~4 workgroups per CU (18 KB LDS, <64 VGPRs each) so that staging latency is covered
+    int64_t nchunk = (1024 + ntiles - 1) / ntiles;
+    if (nchunk > ksteps) nchunk = ksteps;
+    if (nchunk < 1) nchunk = 1;
+    const int64_t steps_per_chunk = (ksteps + nchunk - 1) / nchunk;
+    pl.chunk = steps_per_chunk * DKT;
+    pl.nchunk = (int)((K + pl.chunk - 1) / pl.chunk);
+    size_t bytes = 0;
+    for (int p = 0; p < nprob; ++p) {
+        pl.partial_off[p] = bytes;
+        bytes += align_up((size_t)pl.nchunk * Bx[p] * By[p] * sizeof(float), 256);
+    }
+    pl.ws_bytes = bytes;
+    return pl;
+}
+
+static int run_direct(CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes,
+                      bool partial_only, hipStream_t st) {
+    int Bx[3], By[3], same[3];
+    for (int p = 0; p < cb.nprob; ++p) { Bx[p] = cb.p[p].Bx; By[p] = cb.p[p].By; same[p] = cb.p[p].same; }
+    CostPlan pl = plan_direct(cb.nprob, Bx, By, same, K);
+    if (ws_bytes < pl.ws_bytes || !ws)
+        return fail(KCCOT_EWORKSPACE, "pairwise_cost: workspace %zu < required %zu", ws_bytes, pl.ws_bytes);
+    int total_tiles = 0, max_elems = 0;
+    for (int p = 0; p < cb.nprob; ++p) {
+        CostProb& pr = cb.p[p];
+        pr.tile = DT;
+        pr.tiles_i = (pr.Bx + DT - 1) / DT;
+        pr.tiles_j = (pr.By + DT - 1) / DT;
+        pr.partial = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.partial_off[p]);
+        total_tiles += pr.tiles_i * pr.tiles_j;
+        if (pr.Bx * pr.By > max_elems) max_elems = pr.Bx * pr.By;
+    }
+    if (total_tiles > 65535) return fail(KCCOT_EUNSUPPORTED, "pairwise_cost: %d tiles", total_tiles);
+    bool vec = (K % 4 == 0);
+    for (int p = 0; p < cb.nprob; ++p)
+        vec = vec && (((uintptr_t)cb.p[p].x | (uintptr_t)cb.p[p].y) % 16 == 0);
+    dim3 grid(pl.nchunk, total_tiles);
+    hipLaunchKernelGGL(cost_direct_partial, grid, dim3(256), 0, st, cb, K, pl.chunk, vec ? 1 : 0);
+    int rc = launch_status("cost_direct_partial");
+    if (rc || partial_only) return rc;
+    dim3 fgrid((max_elems + 255) / 256, cb.nprob);
+    hipLaunchKernelGGL(cost_finalize, fgrid, dim3(256), 0, st, cb, pl.nchunk, sc, T, J);
+    return launch_status("cost_finalize");
+}
+
+static int run_cost(CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J, unsigned flags,
+                    void* ws, size_t ws_bytes, hipStream_t st) {
+    if ((flags & KCCOT_COST_FORCE_DIRECT) && (flags & KCCOT_COST_FORCE_MFMA))
+        return fail(KCCOT_EINVAL, "pairwise_cost: FORCE_DIRECT and FORCE_MFMA are exclusive");
+    bool mfma;
+    if (flags & KCCOT_COST_FORCE_MFMA) {
+        if (!gram_eligible(cb, K, loss3))
+            return fail(KCCOT_EUNSUPPORTED, "pairwise_cost: the MFMA path needs 16-byte aligned rows "
+                        "(K %% 4 == 0) and at most 64 rows per operand (128 for x==y)");
+        mfma = true;
+    } else if (flags & KCCOT_COST_FORCE_DIRECT) {
+        mfma = false;
+    } else {
+        mfma = gram_preferred(cb, K, loss3);
+    }
+    const bool partial_only = (flags & KCCOT_COST_PARTIAL_ONLY) != 0;
+    if (mfma) return run_gram(cb, loss3, K, sc, T, J, ws, ws_bytes, partial_only, st);
+    return run_direct(cb, K, sc, T, J, ws, ws_bytes, partial_only, st);
+}
+
+}  // namespace kccot
+
+using namespace kccot;
+
+extern "C" size_t kccot_pairwise_cost_workspace_bytes(int Bx, int By, int64_t K) {
+    if (Bx <= 0 || By <= 0 || K <= 0) return 0;
+    // sized for the larger of the two paths so that the path may be chosen at call time
+    int same = 0;
+    size_t a = plan_direct(1, &Bx, &By, &same, K).ws_bytes;
+    size_t b = plan_gram(K).ws_bytes;
+    return a > b ? a : b;
+}
+
+extern "C" int kccot_pairwise_cost_f32(const float* x, const float* y, int Bx, int By, int64_t K, float sc,
+                                       const float* h1, const float* M1, const float* h2,
+                                       const float* M2, int T, int J, unsigned flags, float* C_out,
+                                       void* ws, size_t ws_bytes, kccot_stream_t stream) {
+    if (!x || !y || !C_out) return fail(KCCOT_EINVAL, "pairwise_cost: null pointer");
+    if (Bx <= 0 || By <= 0 || K <= 0)
+        return fail(KCCOT_EINVAL, "pairwise_cost: bad shape Bx=%d By=%d K=%lld", Bx, By, (long long)K);
+    if ((h1 == nullptr) != (M1 == nullptr) || (h2 == nullptr) != (M2 == nullptr))
+        return fail(KCCOT_EINVAL, "pairwise_cost: h and M must be given together");
+    if ((h1 || h2) && (T < 1 || J < 1)) return fail(KCCOT_EINVAL, "pairwise_cost: bad T=%d J=%d", T, J);
+    if ((flags & KCCOT_COST_SAME) && (x != y || Bx != By))
+        return fail(KCCOT_EINVAL, "pairwise_cost: KCCOT_COST_SAME needs x == y and Bx == By");
+    CostBatch cb{};
+    cb.nprob = 1;
+    cb.p[0] = CostProb{x, y, Bx, By, (flags & KCCOT_COST_SAME) ? 1 : 0, h1, M1, h2, M2, C_out, nullptr, 0, 0, 0};
+    return run_cost(cb, false, K, sc, T, J, flags, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t kccot_pairwise_cost3_workspace_bytes(int B, int64_t K) {
+    if (B <= 0 || K <= 0) return 0;
+    int Bs[3] = {B, B, B}, same[3] = {0, 1, 1};
+    size_t a = plan_direct(3, Bs, Bs, same, K).ws_bytes;
+    size_t b = plan_gram(K).ws_bytes;
+    return a > b ? a : b;
+}
+
+extern "C" int kccot_pairwise_cost3_f32(const float* real, const float* fake, int B, int64_t K, float sc,
+                                        const float* h_fake, const float* h_real, const float* m_real,
+                                        const float* m_fake, int T, int J, unsigned flags, float* C3,
+                                        void* ws, size_t ws_bytes, kccot_stream_t stream) {
+    if (!real || !fake || !C3 || !h_fake || !h_real || !m_real || !m_fake)
+        return fail(KCCOT_EINVAL, "pairwise_cost3: null pointer");
+    if (B <= 0 || K <= 0 || T < 1 || J < 1)
+        return fail(KCCOT_EINVAL, "pairwise_cost3: bad shape B=%d K=%lld T=%d J=%d", B, (long long)K, T, J);
+    const int64_t bb = (int64_t)B * B;
+    CostBatch cb{};
+    cb.nprob = 3;
+    // gan_utils.py:221-223: xy=(real,fake,h_fake,m_real) xx=(real,real,h_real,m_real) yy=(fake,fake,h_fake,m_fake)
+    cb.p[0] = CostProb{real, fake, B, B, 0, h_fake, m_real, nullptr, nullptr, C3, nullptr, 0, 0, 0};
+    cb.p[1] = CostProb{real, real, B, B, 1, h_real, m_real, nullptr, nullptr, C3 + bb, nullptr, 0, 0, 0};
+    cb.p[2] = CostProb{fake, fake, B, B, 1, h_fake, m_fake, nullptr, nullptr, C3 + 2 * bb, nullptr, 0, 0, 0};
+    return run_cost(cb, true, K, sc, T, J, flags, ws, ws_bytes, (hipStream_t)stream);
+}

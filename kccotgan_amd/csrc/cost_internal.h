@@ -1,0 +1,82 @@
+// Internal descriptors shared by cost.hip (direct-difference path + dispatch) and
+// cost_mfma.hip (stacked-Gram f32-MFMA path).
+#pragma once
+#include "common.h"
+
+namespace kccot {
+
+struct CostProb {
+    const float* x;   // rows  [Bx,K]
+    const float* y;   // cols  [By,K]
+    int Bx, By;
+    int same;         // x is y: only tiles on/above the diagonal are computed
+    const float* h1;  // causal term 1: h1 [Bx,T,J] rows, M1 [By,T,J] cols (or null)
+    const float* M1;
+    const float* h2;  // bi-causal second term (or null)
+    const float* M2;
+    float* out;       // [Bx,By]
+    float* partial;   // direct path: [nchunk,Bx,By] partial sums of (x-y)^2
+    int tile, tiles_i, tiles_j;
+};
+
+struct CostBatch {
+    CostProb p[3];
+    int nprob;
+};
+
+struct CostPlan {
+    bool use_mfma;
+    int tile;
+    int64_t chunk;
+    int nchunk;
+    size_t partial_off[3];
+    size_t ws_bytes;
+};
+
+__device__ __forceinline__ float causal_dot(const float* __restrict__ h, const float* __restrict__ M,
+                                            int i, int j, int T, int J) {
+    // sum_{t<T-1} sum_q h[i,t,q]*(M[j,t+1,q]-M[j,t,q]); inner sum over q first, as gan_utils.py:37-38
+    const float* hi = h + (int64_t)i * T * J;
+    const float* Mj = M + (int64_t)j * T * J;
+    float tot = 0.f;
+    for (int t = 0; t < T - 1; ++t) {
+        float s = 0.f;
+        for (int q = 0; q < J; ++q) s = fmaf(hi[t * J + q], Mj[(t + 1) * J + q] - Mj[t * J + q], s);
+        tot += s;
+    }
+    return tot;
+}
+
+
+// ---- stacked-Gram MFMA path (cost_mfma.hip) -------------------------------------------------
+// One "stack" is up to 128 rows: rows 0..63 from src1 (n1 valid), rows 64..127 from src2 (n2
+// valid).  Its Gram matrix is produced as 32x32 sub-tiles (a,b), a <= b < 4, index
+// sub_index(a,b); `mask` selects the sub-tiles that are needed.
+constexpr int GRAM_ROWS = 128;
+constexpr int GRAM_KT = 32;
+constexpr int GRAM_NSUB = 10;
+constexpr int GRAM_REDUCE_SPLIT = 8;
+
+__host__ __device__ inline int sub_index(int a, int b) { return a * 4 - a * (a - 1) / 2 + (b - a); }
+
+struct GramPlan {
+    int64_t chunk;
+    int nchunk;
+    size_t gpart_bytes;   // [nchunk][GRAM_NSUB][1024] float
+    size_t gsum_bytes;    // [GRAM_REDUCE_SPLIT][GRAM_NSUB*1024] double
+    size_t ws_bytes;
+};
+
+enum GramMode {
+    GRAM_LOSS3 = 0,   // src1 = real, src2 = fake, pair-difference stack [X; Y-X]; outputs xy, xx, yy
+    GRAM_XY = 1,      // src1 = x, src2 = y, plain stack; output xy
+    GRAM_SAME = 2,    // src1 = x rows 0..63, src2 = x rows 64..127; output xx (symmetric)
+};
+
+bool gram_eligible(const CostBatch& cb, int64_t K, bool loss3);
+bool gram_preferred(const CostBatch& cb, int64_t K, bool loss3);
+GramPlan plan_gram(int64_t K);
+int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J, void* ws,
+             size_t ws_bytes, bool partial_only, hipStream_t st);
+
+}  // namespace kccot

@@ -1,0 +1,378 @@
+// Stacked-Gram pairwise cost on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32, exact fp32 fma chain).
+//
+// For operands of at most 64 rows each (BASELINE configs[1]: B = 64) the two operands are
+// stacked into one 128-row panel Z and ONE workgroup per K-chunk produces the partial Gram
+// matrix Z Z^T of its chunk as 32x32 sub-tiles on/above the diagonal, so every input element is
+// read from HBM exactly once for all three matrices of the mixed Sinkhorn divergence
+// (gan_utils.py:221-223).  The squared distances are then formed from the chunk-summed Gram
+// entries in fp64 (gram_finalize):  ||z_s - z_t||^2 = G_ss + G_tt - 2 G_st, whose diagonal is
+// exactly 0 as in the reference's direct (x-y)^2 form (gan_utils.py:16).
+//
+// Cancellation.  In the GAN regime fake_i is close to real_i, and G_ss + G_tt - 2 G_st would lose
+// the small distance under the fp32 rounding of three O(K) numbers.  For the loss (GRAM_LOSS3) the
+// stack is therefore [X ; E] with E = fake - real formed in registers while staging (row i of
+// both tensors is held by the same thread), and
+//     D_xy[i,j] = D_xx[i,j] + G_ee[j,j] - 2 (G_xe[i,j] - G_xe[j,j])
+//     D_yy[i,j] = D_xx[i,j] + D_ee[i,j] + 2 (G_xe[i,i] - G_xe[i,j] - G_xe[j,i] + G_xe[j,j])
+// are identities in which every term that must cancel is itself small when E is small; when E is
+// not small they cost nothing.  D_xy[j,j] = G_ee[j,j] = sum_k e_jk^2 is a sum of squares.
+//
+// MFMA fragment maps (cdna_hip_programming.md section 3): for mfma_f32_32x32x2f32 lane l supplies
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; accumulator register r of lane l is
+// D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].  With A[i][k] = Z[32a+i][k] and B[k][j] = Z[32b+j][k]
+// the result is the Gram sub-tile (a,b).  Each lane reads 4 consecutive k of its row with one
+// ds_read_b128 (k = kk + 4*(l>>5) + {0..3}); A and B use the same k mapping, and a sum over k does
+// not care in which order the eight k of a group are visited.
+#include "common.h"
+#include "cost_internal.h"
+#include <stdlib.h>
+
+namespace kccot {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GPITCH = GRAM_KT + 4;   // 36 floats: conflict-free ds_read_b128 over 32 rows
+constexpr int GRAM_SLABS = 12;        // 10 sub-tiles + 2 second halves of the k-split ones
+constexpr int GRAM_ELEMS = GRAM_NSUB * 1024;
+
+struct GramArgs {
+    const float* src1;
+    const float* src2;
+    int n1, n2;
+    int pair_diff;
+    unsigned mask;       // needed sub-tiles, bit sub_index(a,b)
+    int64_t K, chunk;
+    float* gpart;        // [nchunk][GRAM_SLABS][1024]
+};
+
+struct WaveWork {        // up to three (sub-tile, k-group range) entries per wave
+    int a[3], b[3], slab[3], lo[3], hi[3];
+    int n;
+};
+
+__device__ __forceinline__ void sub_ab(int idx, int& a, int& b) {
+    if (idx < 4) { a = 0; b = idx; }
+    else if (idx < 7) { a = 1; b = idx - 3; }
+    else if (idx < 9) { a = 2; b = idx - 5; }
+    else { a = 3; b = 3; }
+}
+
+__device__ __forceinline__ int nth_set_bit(unsigned mask, int n) {
+    for (int idx = 0; idx < GRAM_NSUB; ++idx)
+        if ((mask >> idx) & 1u) {
+            if (n == 0) return idx;
+            --n;
+        }
+    return -1;
+}
+
+// Every field is written with a compile-time index (a runtime-indexed register array would be
+// demoted to scratch memory).
+__device__ __forceinline__ WaveWork wave_work(unsigned mask, int wave) {
+    WaveWork w;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { w.a[s] = w.b[s] = w.slab[s] = 0; w.lo[s] = 0; w.hi[s] = 0; }
+    if (mask == 0x3FFu) {
+        // all ten sub-tiles: two whole ones per wave plus one half (in k) of sub-tile 8 or 9,
+        // i.e. 2.5 sub-tiles of MFMA work on every SIMD
+        sub_ab(2 * wave, w.a[0], w.b[0]);     w.slab[0] = 2 * wave;     w.lo[0] = 0; w.hi[0] = 4;
+        sub_ab(2 * wave + 1, w.a[1], w.b[1]); w.slab[1] = 2 * wave + 1; w.lo[1] = 0; w.hi[1] = 4;
+        const int split = 8 + (wave >> 1), second = wave & 1;
+        sub_ab(split, w.a[2], w.b[2]);
+        w.slab[2] = second ? 10 + (wave >> 1) : split;
+        w.lo[2] = second ? 2 : 0;
+        w.hi[2] = second ? 4 : 2;
+        w.n = 3;
+        return w;
+    }
+    // fewer sub-tiles (at most 9): deal them round-robin, whole
+    const int i0 = nth_set_bit(mask, wave), i1 = nth_set_bit(mask, wave + 4), i2 = nth_set_bit(mask, wave + 8);
+    w.n = (i0 >= 0) + (i1 >= 0) + (i2 >= 0);
+    if (i0 >= 0) { sub_ab(i0, w.a[0], w.b[0]); w.slab[0] = i0; w.hi[0] = 4; }
+    if (i1 >= 0) { sub_ab(i1, w.a[1], w.b[1]); w.slab[1] = i1; w.hi[1] = 4; }
+    if (i2 >= 0) { sub_ab(i2, w.a[2], w.b[2]); w.slab[2] = i2; w.hi[2] = 4; }
+    return w;
+}
+
+__device__ __forceinline__ float4 ld4(const float* __restrict__ row, int64_t k, int64_t kend, bool ok) {
+    if (ok && k + 4 <= kend) return *reinterpret_cast<const float4*>(row + k);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+#define KCCOT_MFMA4(ACC, A4, B4)                                              \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A4.x, B4.x, ACC, 0, 0, 0);     \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A4.y, B4.y, ACC, 0, 0, 0);     \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A4.z, B4.z, ACC, 0, 0, 0);     \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A4.w, B4.w, ACC, 0, 0, 0);
+
+__global__ __launch_bounds__(256) void gram128_partial(GramArgs ga) {
+    __shared__ __attribute__((aligned(16))) float zs[GRAM_ROWS * GPITCH];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t kbeg = (int64_t)blockIdx.x * ga.chunk;
+    const int64_t kend = (kbeg + ga.chunk < ga.K) ? kbeg + ga.chunk : ga.K;
+    if (kbeg >= kend) return;
+
+    // staging: thread holds the float4 at columns c4..c4+3 of stack rows r0, r0+32, 64+r0, 96+r0
+    const int r0 = t >> 3, c4 = (t & 7) * 4;
+    const bool ok0 = r0 < ga.n1, ok1 = r0 + 32 < ga.n1, ok2 = r0 < ga.n2, ok3 = r0 + 32 < ga.n2;
+    const float* p0 = ga.src1 + (int64_t)r0 * ga.K;
+    const float* p1 = ga.src1 + (int64_t)(r0 + 32) * ga.K;
+    const float* p2 = ga.src2 + (int64_t)r0 * ga.K;
+    const float* p3 = ga.src2 + (int64_t)(r0 + 32) * ga.K;
+
+    const WaveWork ww = wave_work(ga.mask, wave);
+    const int arow0 = (ww.a[0] * 32 + (lane & 31)) * GPITCH + 4 * (lane >> 5);
+    const int brow0 = (ww.b[0] * 32 + (lane & 31)) * GPITCH + 4 * (lane >> 5);
+    const int arow1 = (ww.a[1] * 32 + (lane & 31)) * GPITCH + 4 * (lane >> 5);
+    const int brow1 = (ww.b[1] * 32 + (lane & 31)) * GPITCH + 4 * (lane >> 5);
+    const int arow2 = (ww.a[2] * 32 + (lane & 31)) * GPITCH + 4 * (lane >> 5);
+    const int brow2 = (ww.b[2] * 32 + (lane & 31)) * GPITCH + 4 * (lane >> 5);
+
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+
+    float4 v0 = ld4(p0, kbeg + c4, kend, ok0);
+    float4 v1 = ld4(p1, kbeg + c4, kend, ok1);
+    float4 v2 = ld4(p2, kbeg + c4, kend, ok2);
+    float4 v3 = ld4(p3, kbeg + c4, kend, ok3);
+
+    for (int64_t k0 = kbeg; k0 < kend; k0 += GRAM_KT) {
+        if (ga.pair_diff) {  // E = src2 - src1 (n1 == n2, so a row is valid in both or in neither)
+            v2.x -= v0.x; v2.y -= v0.y; v2.z -= v0.z; v2.w -= v0.w;
+            v3.x -= v1.x; v3.y -= v1.y; v3.z -= v1.z; v3.w -= v1.w;
+        }
+        *reinterpret_cast<float4*>(&zs[r0 * GPITCH + c4]) = v0;
+        *reinterpret_cast<float4*>(&zs[(r0 + 32) * GPITCH + c4]) = v1;
+        *reinterpret_cast<float4*>(&zs[(r0 + 64) * GPITCH + c4]) = v2;
+        *reinterpret_cast<float4*>(&zs[(r0 + 96) * GPITCH + c4]) = v3;
+        __syncthreads();
+        const int64_t kn = k0 + GRAM_KT;
+        if (kn < kend) {  // next stage's HBM reads fly under this stage's MFMAs
+            v0 = ld4(p0, kn + c4, kend, ok0);
+            v1 = ld4(p1, kn + c4, kend, ok1);
+            v2 = ld4(p2, kn + c4, kend, ok2);
+            v3 = ld4(p3, kn + c4, kend, ok3);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // four groups of 8 k
+            if (ww.n > 0 && g >= ww.lo[0] && g < ww.hi[0]) {
+                const float4 A = *reinterpret_cast<const float4*>(&zs[arow0 + 8 * g]);
+                const float4 B = *reinterpret_cast<const float4*>(&zs[brow0 + 8 * g]);
+                KCCOT_MFMA4(acc0, A, B)
+            }
+            if (ww.n > 1 && g >= ww.lo[1] && g < ww.hi[1]) {
+                const float4 A = *reinterpret_cast<const float4*>(&zs[arow1 + 8 * g]);
+                const float4 B = *reinterpret_cast<const float4*>(&zs[brow1 + 8 * g]);
+                KCCOT_MFMA4(acc1, A, B)
+            }
+            if (ww.n > 2 && g >= ww.lo[2] && g < ww.hi[2]) {
+                const float4 A = *reinterpret_cast<const float4*>(&zs[arow2 + 8 * g]);
+                const float4 B = *reinterpret_cast<const float4*>(&zs[brow2 + 8 * g]);
+                KCCOT_MFMA4(acc2, A, B)
+            }
+        }
+        __syncthreads();
+    }
+
+    // accumulator register r of lane l is element ((r&3) + 8*(r>>2) + 4*(l>>5), l&31)
+    float* base = ga.gpart + (int64_t)blockIdx.x * GRAM_SLABS * 1024;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    if (ww.n > 0) {
+        float* o = base + ww.slab[0] * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc0[r];
+    }
+    if (ww.n > 1) {
+        float* o = base + ww.slab[1] * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc1[r];
+    }
+    if (ww.n > 2) {
+        float* o = base + ww.slab[2] * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc2[r];
+    }
+}
+
+// Sum the per-chunk partial Gram sub-tiles in fp64.  grid = (GRAM_ELEMS/256, GRAM_REDUCE_SPLIT):
+// block (e, r) sums chunks r, r+SPLIT, ... in increasing order -> deterministic.
+__global__ __launch_bounds__(256) void gram_reduce(const float* __restrict__ gpart, int nchunk,
+                                                   unsigned mask, double* __restrict__ gsum) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int sub = e >> 10;
+    double s = 0.0;
+    if ((mask >> sub) & 1u) {
+        const bool split = (mask == 0x3FFu) && sub >= 8;   // second k-half lives in slab sub+2
+        for (int c = blockIdx.y; c < nchunk; c += GRAM_REDUCE_SPLIT) {
+            const float* p = gpart + (int64_t)c * GRAM_SLABS * 1024;
+            s += (double)p[e];
+            if (split) s += (double)p[e + 2048];
+        }
+    }
+    gsum[(int64_t)blockIdx.y * GRAM_ELEMS + e] = s;
+}
+
+struct GramFin {
+    const double* gsum;
+    int mode;
+    int B1, B2;          // output rows / cols
+    float* out[3];
+    const float* h[3];   // causal term per output (rows), or null
+    const float* M[3];
+    const float* h2;     // bi-causal second term (GRAM_XY only)
+    const float* M2;
+    float sc;
+    int T, J;
+};
+
+__device__ __forceinline__ double gram_at(const double* __restrict__ gsum, int s, int t) {
+    int a = s >> 5, b = t >> 5;
+    if (a > b) { int x = s; s = t; t = x; x = a; a = b; b = x; }
+    const int e = sub_index(a, b) * 1024 + (s & 31) * 32 + (t & 31);
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < GRAM_REDUCE_SPLIT; ++r) v += gsum[(int64_t)r * GRAM_ELEMS + e];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
+    const int p = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= f.B1 * f.B2) return;
+    const int i = e / f.B2, j = e % f.B2;
+    const double* G = f.gsum;
+    double D;
+    if (f.mode == GRAM_LOSS3) {
+        const double dxx = (i == j) ? 0.0 : gram_at(G, i, i) + gram_at(G, j, j) - 2.0 * gram_at(G, i, j);
+        if (p == 1) {
+            D = dxx;
+        } else if (p == 0) {
+            D = dxx + gram_at(G, 64 + j, 64 + j) - 2.0 * (gram_at(G, i, 64 + j) - gram_at(G, j, 64 + j));
+        } else {
+            if (i == j) D = 0.0;
+            else {
+                const double dee = gram_at(G, 64 + i, 64 + i) + gram_at(G, 64 + j, 64 + j)
+                                   - 2.0 * gram_at(G, 64 + i, 64 + j);
+                D = dxx + dee + 2.0 * (gram_at(G, i, 64 + i) - gram_at(G, i, 64 + j)
+                                       - gram_at(G, j, 64 + i) + gram_at(G, j, 64 + j));
+            }
+        }
+    } else if (f.mode == GRAM_XY) {
+        D = gram_at(G, i, i) + gram_at(G, 64 + j, 64 + j) - 2.0 * gram_at(G, i, 64 + j);
+    } else {  // GRAM_SAME: row i of x is stack row i (rows 64.. come from src2 = x + 64 rows)
+        D = (i == j) ? 0.0 : gram_at(G, i, i) + gram_at(G, j, j) - 2.0 * gram_at(G, i, j);
+    }
+    if (D < 0.0) D = 0.0;   // a squared distance; rounding of the Gram terms may leave -tiny
+    float c = (float)D * f.sc;
+    if (f.h[p]) c += causal_dot(f.h[p], f.M[p], i, j, f.T, f.J) * f.sc;
+    if (p == 0 && f.h2) c += causal_dot(f.h2, f.M2, i, j, f.T, f.J) * f.sc;
+    f.out[p][e] = c;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+bool gram_eligible(const CostBatch& cb, int64_t K, bool loss3) {
+    if (K % 4 != 0 || K < GRAM_KT) return false;
+    for (int p = 0; p < cb.nprob; ++p)
+        if (!aligned16(cb.p[p].x) || !aligned16(cb.p[p].y)) return false;
+    if (loss3) return cb.nprob == 3 && cb.p[0].Bx <= 64;
+    if (cb.nprob != 1) return false;
+    if (cb.p[0].same) return cb.p[0].Bx <= 128;
+    return cb.p[0].Bx <= 64 && cb.p[0].By <= 64;
+}
+
+bool gram_preferred(const CostBatch& cb, int64_t K, bool loss3) {
+    // the direct kernel always computes whole 64x64 tiles on the VALU; the MFMA path skips
+    // 32-row blocks that hold no valid row, so it is preferred whenever it is eligible
+    return gram_eligible(cb, K, loss3) && K >= 256;
+}
+
+static int gram_target_wgs() {
+    const char* e = getenv("KCCOT_GRAM_WGS");   // tuning knob (bench sweeps)
+    int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 512;
+}
+
+GramPlan plan_gram(int64_t K) {
+    GramPlan pl{};
+    const int64_t ksteps = (K + GRAM_KT - 1) / GRAM_KT;
+    int64_t nchunk = gram_target_wgs();
+    if (nchunk > ksteps) nchunk = ksteps;
+    if (nchunk < 1) nchunk = 1;
+    const int64_t spc = (ksteps + nchunk - 1) / nchunk;
+    pl.chunk = spc * GRAM_KT;
+    pl.nchunk = (int)((K + pl.chunk - 1) / pl.chunk);
+    // sized for the largest plan the knob can produce so that the query stays an upper bound
+    int64_t max_chunks = ksteps < 1024 ? ksteps : 1024;
+    if (max_chunks < pl.nchunk) max_chunks = pl.nchunk;
+    pl.gpart_bytes = align_up((size_t)max_chunks * GRAM_SLABS * 1024 * sizeof(float), 256);
+    pl.gsum_bytes = align_up((size_t)GRAM_REDUCE_SPLIT * GRAM_ELEMS * sizeof(double), 256);
+    pl.ws_bytes = pl.gpart_bytes + pl.gsum_bytes;
+    return pl;
+}
+
+static unsigned gram_mask(int mode, int n1, int n2) {
+    bool valid[4] = {n1 > 0, n1 > 32, n2 > 0, n2 > 32};
+    unsigned m = 0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = a; b < 4; ++b) {
+            if (!valid[a] || !valid[b]) continue;
+            bool need = true;
+            if (mode == GRAM_XY) need = (a == b) || (a < 2 && b >= 2);   // norms + the xy block
+            if (need) m |= 1u << sub_index(a, b);
+        }
+    return m;
+}
+
+int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J, void* ws,
+             size_t ws_bytes, bool partial_only, hipStream_t st) {
+    GramPlan pl = plan_gram(K);
+    if (!ws || ws_bytes < pl.ws_bytes)
+        return fail(KCCOT_EWORKSPACE, "pairwise_cost(mfma): workspace %zu < required %zu", ws_bytes, pl.ws_bytes);
+    if (pl.nchunk > 1024) return fail(KCCOT_EUNSUPPORTED, "pairwise_cost(mfma): %d chunks", pl.nchunk);
+    GramArgs ga{};
+    GramFin gf{};
+    const CostProb& p0 = cb.p[0];
+    int mode, nout;
+    if (loss3) {
+        mode = GRAM_LOSS3; nout = 3;
+        ga.src1 = p0.x; ga.src2 = p0.y; ga.n1 = p0.Bx; ga.n2 = p0.By; ga.pair_diff = 1;
+        gf.B1 = p0.Bx; gf.B2 = p0.By;
+        for (int p = 0; p < 3; ++p) { gf.out[p] = cb.p[p].out; gf.h[p] = cb.p[p].h1; gf.M[p] = cb.p[p].M1; }
+    } else if (p0.same) {
+        mode = GRAM_SAME; nout = 1;
+        ga.src1 = p0.x; ga.n1 = p0.Bx < 64 ? p0.Bx : 64;
+        ga.n2 = p0.Bx > 64 ? p0.Bx - 64 : 0;
+        ga.src2 = ga.n2 ? p0.x + (int64_t)64 * K : p0.x;
+        ga.pair_diff = 0;
+        gf.B1 = gf.B2 = p0.Bx;
+        gf.out[0] = p0.out; gf.h[0] = p0.h1; gf.M[0] = p0.M1; gf.h2 = p0.h2; gf.M2 = p0.M2;
+    } else {
+        mode = GRAM_XY; nout = 1;
+        ga.src1 = p0.x; ga.src2 = p0.y; ga.n1 = p0.Bx; ga.n2 = p0.By; ga.pair_diff = 0;
+        gf.B1 = p0.Bx; gf.B2 = p0.By;
+        gf.out[0] = p0.out; gf.h[0] = p0.h1; gf.M[0] = p0.M1; gf.h2 = p0.h2; gf.M2 = p0.M2;
+    }
+    ga.mask = gram_mask(mode, ga.n1, ga.n2);
+    ga.K = K; ga.chunk = pl.chunk;
+    ga.gpart = static_cast<float*>(ws);
+    double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.gpart_bytes);
+    hipLaunchKernelGGL(gram128_partial, dim3(pl.nchunk), dim3(256), 0, st, ga);
+    int rc = launch_status("gram128_partial");
+    if (rc || partial_only) return rc;
+    hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 256, GRAM_REDUCE_SPLIT), dim3(256), 0, st,
+                       (const float*)ga.gpart, pl.nchunk, ga.mask, gsum);
+    rc = launch_status("gram_reduce");
+    if (rc) return rc;
+    gf.gsum = gsum; gf.mode = mode; gf.sc = sc; gf.T = T; gf.J = J;
+    hipLaunchKernelGGL(gram_finalize, dim3((gf.B1 * gf.B2 + 255) / 256, nout), dim3(256), 0, st, gf);
+    return launch_status("gram_finalize");
+}
+
+}  // namespace kccot

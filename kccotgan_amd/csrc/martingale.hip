@@ -1,0 +1,113 @@
+// Martingale penalty p_M and its backward (replaces gan_utils.py:179-201 of the reference):
+//   N = M[:,1:,:] - M[:,:-1,:];  N_std = N / (std_{b,t}(M)[q] + 1e-6)   (population std)
+//   s[t,q] = (1/B) sum_b N_std[b,t,q];  pM = lam * (sum_{t,q} |s[t,q]| * sc)
+// A [B,T,J] feature tensor is a few thousand floats: one workgroup, everything staged in LDS.
+#include "common.h"
+#include <math.h>
+
+namespace kccot {
+
+// LDS layout (dynamic): mean[J] | stdv[J] | sabs[J] | s[(T-1)*J] | red[16]
+__device__ __forceinline__ void martingale_stats(const float* __restrict__ M, int B, int T, int J,
+                                                 float* mean, float* stdv, float* sabs, float* s) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int BT = B * T;
+    for (int q = wid; q < J; q += nw) {
+        float a = 0.f;
+        for (int e = lane; e < BT; e += 64) a += M[(int64_t)e * J + q];
+        const float mu = wave_sum(a) / (float)BT;
+        float v = 0.f;
+        for (int e = lane; e < BT; e += 64) {
+            const float d = M[(int64_t)e * J + q] - mu;
+            v = fmaf(d, d, v);
+        }
+        const float var = wave_sum(v) / (float)BT;
+        if (lane == 0) { mean[q] = mu; stdv[q] = sqrtf(var); sabs[q] = 0.f; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < (T - 1) * J; e += blockDim.x) {
+        const int q = e % J, t = e / J;
+        const float den = stdv[q] + 1e-06f;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const int64_t o = ((int64_t)b * T + t) * J + q;
+            acc += (M[o + J] - M[o]) / den;
+        }
+        s[e] = acc / (float)B;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void martingale_fwd(const float* __restrict__ M, int B, int T, int J, float lam,
+                                                       float sc, float* __restrict__ pm_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* mean = smem; float* stdv = mean + J; float* sabs = stdv + J; float* s = sabs + J;
+    float* red = s + (T - 1) * J;
+    martingale_stats(M, B, T, J, mean, stdv, sabs, s);
+    float part = 0.f;
+    for (int e = threadIdx.x; e < (T - 1) * J; e += blockDim.x) part += fabsf(s[e]);
+    const float tot = block_sum(part, red);
+    if (threadIdx.x == 0) pm_out[0] = lam * (tot * sc);
+}
+
+// dpM/dM[b,tau,q] = lam*sc * { [sgn(s[tau-1,q]) [tau>=1] - sgn(s[tau,q]) [tau<=T-2]] / (B (std_q+1e-6))
+//                             - (sum_t |s[t,q]|) / (std_q+1e-6) * (M[b,tau,q]-mean_q) / (B T std_q) }
+// (second line: the path through std; d std/dM = (M-mean)/(N std), as the gradient of
+//  tf.math.reduce_std = sqrt(reduce_variance); taken as 0 where std = 0.)
+__global__ __launch_bounds__(1024) void martingale_bwd(const float* __restrict__ M, int B, int T, int J, float lam,
+                                                       float sc, const float* __restrict__ gpm, float* __restrict__ dM) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* mean = smem; float* stdv = mean + J; float* sabs = stdv + J; float* s = sabs + J;
+    martingale_stats(M, B, T, J, mean, stdv, sabs, s);
+    for (int q = threadIdx.x; q < J; q += blockDim.x) {
+        float a = 0.f;
+        for (int t = 0; t < T - 1; ++t) a += fabsf(s[t * J + q]);
+        sabs[q] = a;
+    }
+    __syncthreads();
+    const float k = gpm[0] * lam * sc;
+    const int n = B * T * J;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int q = e % J, tau = (e / J) % T;
+        const float den = stdv[q] + 1e-06f;
+        float sg = 0.f;
+        if (tau >= 1) { const float v = s[(tau - 1) * J + q]; sg += (v > 0.f) - (v < 0.f); }
+        if (tau <= T - 2) { const float v = s[tau * J + q]; sg -= (v > 0.f) - (v < 0.f); }
+        float g = sg / ((float)B * den);
+        if (stdv[q] > 0.f)
+            g -= sabs[q] / den * (M[e] - mean[q]) / ((float)B * (float)T * stdv[q]);
+        dM[e] = k * g;
+    }
+}
+
+}  // namespace kccot
+
+using namespace kccot;
+
+static int martingale_check(const float* M, int B, int T, int J, size_t* lds) {
+    if (!M) return fail(KCCOT_EINVAL, "martingale: null pointer");
+    if (B <= 0 || T < 1 || J < 1) return fail(KCCOT_EINVAL, "martingale: bad shape B=%d T=%d J=%d", B, T, J);
+    *lds = ((size_t)3 * J + (size_t)(T - 1) * J + 16) * sizeof(float);
+    if (*lds > 64 * 1024) return fail(KCCOT_EUNSUPPORTED, "martingale: T*J = %d too large for one workgroup", T * J);
+    return 0;
+}
+
+extern "C" int kccot_martingale_fwd_f32(const float* M, int B, int T, int J, float lam, float sc, float* pm_out,
+                                        kccot_stream_t stream) {
+    size_t lds;
+    int rc = martingale_check(M, B, T, J, &lds);
+    if (rc) return rc;
+    if (!pm_out) return fail(KCCOT_EINVAL, "martingale_fwd: null output");
+    hipLaunchKernelGGL(martingale_fwd, dim3(1), dim3(1024), lds, (hipStream_t)stream, M, B, T, J, lam, sc, pm_out);
+    return launch_status("martingale_fwd");
+}
+
+extern "C" int kccot_martingale_bwd_f32(const float* M, int B, int T, int J, float lam, float sc, const float* gpm,
+                                        float* dM, kccot_stream_t stream) {
+    size_t lds;
+    int rc = martingale_check(M, B, T, J, &lds);
+    if (rc) return rc;
+    if (!gpm || !dM) return fail(KCCOT_EINVAL, "martingale_bwd: null pointer");
+    hipLaunchKernelGGL(martingale_bwd, dim3(1), dim3(1024), lds, (hipStream_t)stream, M, B, T, J, lam, sc, gpm, dM);
+    return launch_status("martingale_bwd");
+}

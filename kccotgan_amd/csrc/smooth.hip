@@ -1,0 +1,248 @@
+// Gaussian kernel smoothing of [B,H,T,W,C] video tensors (replaces KernelSmoothing of the
+// reference, data_utils.py:478-582): normalised (2r+1)-tap Gaussian along T (temporal_convolution)
+// or along T, H and W (gaussian_convolution3D -- its 7x7x7 kernel, data_utils.py:493-501, is the
+// outer product of the 1-D kernel), REFLECT borders (data_utils.py:512-513,562-565), then division
+// by the maximum of the whole smoothed tensor (data_utils.py:520,573,581).
+//
+// The reference reaches the conv through four physical transposes and a padded copy; here every
+// axis is convolved in place on the native layout: along any axis consecutive threads touch
+// consecutive addresses (W*C is innermost), the 2r neighbour lines come from L1/L2.
+// This is the first, pass-per-axis version: HBM traffic is one read + one write of the tensor
+// per axis plus the max/scale pass (algorithmic minimum: one read + one write in total).
+#include "common.h"
+#include <math.h>
+#include <float.h>
+
+namespace kccot {
+
+constexpr int SM_MAXR = 7;
+
+struct Taps { float w[2 * SM_MAXR + 1]; int r; };
+
+// data_utils.py:483-491: kernel = exp(-0.5/sigma^2 * x^2) (fp32), normalised by its fp32 sum
+static Taps make_taps(float sigma, int r) {
+    Taps tp{};
+    tp.r = r;
+    const float coef = (float)(-0.5 / ((double)sigma * (double)sigma));
+    float sum = 0.f;
+    for (int d = -r; d <= r; ++d) { tp.w[d + r] = expf(coef * (float)(d * d)); sum += tp.w[d + r]; }
+    for (int d = 0; d <= 2 * r; ++d) tp.w[d] /= sum;
+    return tp;
+}
+
+__device__ __forceinline__ int reflect(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * (len - 1) - p : p); }
+
+// out[e] = sum_d w[d] * in[e with its axis position moved to reflect(p+d)]           (adjoint = 0)
+// out[e] = sum over all (t,d) whose reflected source is p of w[d] * in[.. t ..]      (adjoint = 1)
+// If blockmax != null also writes the maximum of the block's outputs (forward, last axis).
+__global__ __launch_bounds__(256) void conv_axis(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                 int len, int64_t stride, Taps tp, int adjoint,
+                                                 float* __restrict__ blockmax) {
+    __shared__ float red[16];
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    const bool ok = e < n;
+    if (ok) {
+        const int p = (int)((e / stride) % len);
+        const float* base = in + (e - (int64_t)p * stride);
+        const int r = tp.r;
+        if (!adjoint) {
+            for (int d = -r; d <= r; ++d) acc = fmaf(tp.w[d + r], base[(int64_t)reflect(p + d, len) * stride], acc);
+        } else {
+            for (int d = -r; d <= r; ++d) {
+                const float w = tp.w[d + r];
+                int t = p - d;
+                if (t >= 0 && t < len) acc = fmaf(w, base[(int64_t)t * stride], acc);
+                t = -p - d;
+                if (p >= 1 && t >= 0 && t < len) acc = fmaf(w, base[(int64_t)t * stride], acc);
+                t = 2 * (len - 1) - p - d;
+                if (p <= len - 2 && t >= 0 && t < len) acc = fmaf(w, base[(int64_t)t * stride], acc);
+            }
+        }
+        out[e] = acc;
+    }
+    if (blockmax) {
+        const float m = block_max(ok ? acc : -FLT_MAX, red);
+        if (threadIdx.x == 0) blockmax[blockIdx.x] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_with_blockmax(const float* __restrict__ in, float* __restrict__ out,
+                                                          int64_t n, float* __restrict__ blockmax) {
+    __shared__ float red[16];
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = e < n;
+    const float v = ok ? in[e] : -FLT_MAX;
+    if (ok && out != in) out[e] = v;
+    const float m = block_max(v, red);
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = m;
+}
+
+__global__ __launch_bounds__(1024) void reduce_blockmax(const float* __restrict__ blockmax, int64_t nb,
+                                                        float* __restrict__ max_out) {
+    __shared__ float red[16];
+    float m = -FLT_MAX;
+    for (int64_t i = threadIdx.x; i < nb; i += blockDim.x) m = fmaxf(m, blockmax[i]);
+    m = block_max(m, red);
+    if (threadIdx.x == 0) max_out[0] = m;
+}
+
+__global__ __launch_bounds__(256) void divide_by(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                 const float* __restrict__ mx) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = in[e] / mx[0];
+}
+
+// backward of out = s / max(s):  ds = gout/m - [out == 1] * (sum gout*out) / (m * #ties)
+// stage 1: per-block partial (dot, ties) ; stage 2: combine ; stage 3: elementwise
+__global__ __launch_bounds__(256) void maxnorm_bwd_partial(const float* __restrict__ gout, const float* __restrict__ out,
+                                                           int64_t n, float* __restrict__ pdot, float* __restrict__ pcnt) {
+    __shared__ float red[16];
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = e < n;
+    const float o = ok ? out[e] : 0.f;
+    const float d = block_sum(ok ? gout[e] * o : 0.f, red);
+    const float c = block_sum((ok && o == 1.0f) ? 1.f : 0.f, red);
+    if (threadIdx.x == 0) { pdot[blockIdx.x] = d; pcnt[blockIdx.x] = c; }
+}
+
+__global__ __launch_bounds__(1024) void maxnorm_bwd_combine(const float* __restrict__ pdot, const float* __restrict__ pcnt,
+                                                            int64_t nb, float* __restrict__ res) {
+    __shared__ float red[16];
+    double d = 0.0;
+    float c = 0.f;
+    for (int64_t i = threadIdx.x; i < nb; i += blockDim.x) { d += (double)pdot[i]; c += pcnt[i]; }
+    const float ds = block_sum((float)d, red);
+    const float cs = block_sum(c, red);
+    if (threadIdx.x == 0) { res[0] = ds; res[1] = cs; }
+}
+
+__global__ __launch_bounds__(256) void maxnorm_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
+                                                         int64_t n, const float* __restrict__ mx,
+                                                         const float* __restrict__ res, float* __restrict__ ds) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float m = mx[0];
+    float v = gout[e] / m;
+    if (out[e] == 1.0f && res[1] > 0.f) v -= res[0] / (m * res[1]);
+    ds[e] = v;
+}
+
+struct Axis { int len; int64_t stride; };
+
+static int collect_axes(int H, int T, int W, int C, unsigned flags, Axis* ax) {
+    int na = 0;
+    if (flags & KCCOT_SMOOTH_T) ax[na++] = Axis{T, (int64_t)W * C};
+    if (flags & KCCOT_SMOOTH_H) ax[na++] = Axis{H, (int64_t)T * W * C};
+    if (flags & KCCOT_SMOOTH_W) ax[na++] = Axis{W, (int64_t)C};
+    return na;
+}
+
+}  // namespace kccot
+
+using namespace kccot;
+
+extern "C" size_t kccot_smooth_workspace_bytes(int B, int H, int T, int W, int C) {
+    if (B <= 0 || H <= 0 || T <= 0 || W <= 0 || C <= 0) return 0;
+    const size_t n = (size_t)B * H * T * W * C;
+    const size_t nb = (n + 255) / 256;
+    // one tensor-sized ping-pong buffer + two per-block reduction arrays + 4 scalars
+    return align_up(n * sizeof(float), 256) + 2 * align_up(nb * sizeof(float), 256) + 256;
+}
+
+static int smooth_check(const char* who, const void* a, const void* b, int B, int H, int T, int W, int C, float sigma,
+                        int radius, unsigned flags) {
+    if (!a || !b) return fail(KCCOT_EINVAL, "%s: null pointer", who);
+    if (B <= 0 || H <= 0 || T <= 0 || W <= 0 || C <= 0)
+        return fail(KCCOT_EINVAL, "%s: bad shape [%d,%d,%d,%d,%d]", who, B, H, T, W, C);
+    if (radius < 0 || radius > SM_MAXR) return fail(KCCOT_EUNSUPPORTED, "%s: radius %d > %d", who, radius, SM_MAXR);
+    if (!(sigma > 0.f)) return fail(KCCOT_EINVAL, "%s: sigma must be > 0", who);
+    // REFLECT padding needs pad < dim (tf.pad rejects it otherwise)
+    if (((flags & KCCOT_SMOOTH_T) && radius >= T) || ((flags & KCCOT_SMOOTH_H) && radius >= H) ||
+        ((flags & KCCOT_SMOOTH_W) && radius >= W))
+        return fail(KCCOT_EINVAL, "%s: REFLECT padding needs radius < axis length", who);
+    return 0;
+}
+
+extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W, int C, float sigma, int radius,
+                                    unsigned flags, float* out, float* max_inout, void* ws, size_t ws_bytes,
+                                    kccot_stream_t stream) {
+    int rc = smooth_check("smooth_fwd", in, out, B, H, T, W, C, sigma, radius, flags);
+    if (rc) return rc;
+    if (!max_inout) return fail(KCCOT_EINVAL, "smooth_fwd: null max pointer");
+    const size_t need = kccot_smooth_workspace_bytes(B, H, T, W, C);
+    if (!ws || ws_bytes < need) return fail(KCCOT_EWORKSPACE, "smooth_fwd: workspace %zu < required %zu", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * H * T * W * C;
+    const int64_t nb = (n + 255) / 256;
+    if (nb > 0x7fffffff) return fail(KCCOT_EUNSUPPORTED, "smooth_fwd: tensor too large");
+    float* tmp = static_cast<float*>(ws);
+    float* bmax = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)n * sizeof(float), 256));
+    Axis ax[3];
+    const int na = collect_axes(H, T, W, C, flags, ax);
+    const bool ext = (flags & KCCOT_SMOOTH_EXTERNAL_MAX) != 0, nodiv = (flags & KCCOT_SMOOTH_NO_DIVIDE) != 0;
+    if (ext && nodiv) return fail(KCCOT_EINVAL, "smooth_fwd: EXTERNAL_MAX and NO_DIVIDE are exclusive");
+    if (na > 0 && in == out) return fail(KCCOT_EINVAL, "smooth_fwd: in-place convolution is not supported");
+    const Taps tp = make_taps(sigma, radius);
+    const float* src = in;
+    for (int i = 0; i < na; ++i) {
+        float* dst = ((na - 1 - i) % 2 == 0) ? out : tmp;
+        const bool last = (i == na - 1);
+        hipLaunchKernelGGL(conv_axis, dim3((unsigned)nb), dim3(256), 0, st, src, dst, n, ax[i].len, ax[i].stride, tp, 0,
+                           (last && !ext) ? bmax : (float*)nullptr);
+        if ((rc = launch_status("conv_axis"))) return rc;
+        src = dst;
+    }
+    if (na == 0 && !ext) {   // max (and copy) only
+        hipLaunchKernelGGL(copy_with_blockmax, dim3((unsigned)nb), dim3(256), 0, st, in, out, n, bmax);
+        if ((rc = launch_status("copy_with_blockmax"))) return rc;
+    }
+    if (!ext) {
+        hipLaunchKernelGGL(reduce_blockmax, dim3(1), dim3(1024), 0, st, (const float*)bmax, nb, max_inout);
+        if ((rc = launch_status("reduce_blockmax"))) return rc;
+    }
+    if (!nodiv) {
+        const float* dsrc = (na == 0 && ext) ? in : out;
+        hipLaunchKernelGGL(divide_by, dim3((unsigned)nb), dim3(256), 0, st, dsrc, out, n, (const float*)max_inout);
+        if ((rc = launch_status("divide_by"))) return rc;
+    }
+    return 0;
+}
+
+extern "C" int kccot_smooth_bwd_f32(const float* gout, const float* out, const float* max_in, int B, int H, int T,
+                                    int W, int C, float sigma, int radius, unsigned flags, float* din, void* ws,
+                                    size_t ws_bytes, kccot_stream_t stream) {
+    int rc = smooth_check("smooth_bwd", gout, din, B, H, T, W, C, sigma, radius, flags);
+    if (rc) return rc;
+    if (!out || !max_in) return fail(KCCOT_EINVAL, "smooth_bwd: null pointer");
+    const size_t need = kccot_smooth_workspace_bytes(B, H, T, W, C);
+    if (!ws || ws_bytes < need) return fail(KCCOT_EWORKSPACE, "smooth_bwd: workspace %zu < required %zu", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * H * T * W * C;
+    const int64_t nb = (n + 255) / 256;
+    float* tmp = static_cast<float*>(ws);
+    char* p = static_cast<char*>(ws) + align_up((size_t)n * sizeof(float), 256);
+    float* pdot = reinterpret_cast<float*>(p);
+    float* pcnt = reinterpret_cast<float*>(p + align_up((size_t)nb * sizeof(float), 256));
+    float* res = reinterpret_cast<float*>(p + 2 * align_up((size_t)nb * sizeof(float), 256));
+    Axis ax[3];
+    const int na = collect_axes(H, T, W, C, flags, ax);
+    const Taps tp = make_taps(sigma, radius);
+    // ds goes where the adjoint chain wants its first source: (na passes) ... -> din
+    float* ds = (na % 2 == 0) ? din : tmp;
+    hipLaunchKernelGGL(maxnorm_bwd_partial, dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, pdot, pcnt);
+    if ((rc = launch_status("maxnorm_bwd_partial"))) return rc;
+    hipLaunchKernelGGL(maxnorm_bwd_combine, dim3(1), dim3(1024), 0, st, (const float*)pdot, (const float*)pcnt, nb, res);
+    if ((rc = launch_status("maxnorm_bwd_combine"))) return rc;
+    hipLaunchKernelGGL(maxnorm_bwd_apply, dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, max_in, (const float*)res, ds);
+    if ((rc = launch_status("maxnorm_bwd_apply"))) return rc;
+    const float* src = ds;
+    for (int i = na - 1; i >= 0; --i) {
+        float* dst = (src == tmp) ? din : tmp;
+        hipLaunchKernelGGL(conv_axis, dim3((unsigned)nb), dim3(256), 0, st, src, dst, n, ax[i].len, ax[i].stride, tp, 1,
+                           (float*)nullptr);
+        if ((rc = launch_status("conv_axis(adjoint)"))) return rc;
+        src = dst;
+    }
+    return 0;
+}

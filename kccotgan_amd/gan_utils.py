@@ -1,0 +1,283 @@
+"""Drop-in for the reference's ``gan_utils.py`` -- same function names, argument order, defaults
+and positional behaviour -- with ``torch.Tensor`` on a ROCm device instead of ``tf.Tensor`` and
+the arithmetic done by the hand-written HIP kernels behind ``include/kccot.h``.
+
+Every function cites the reference lines it replaces (``gan_utils.py:LINE`` = /root/reference).
+Differentiable with hand-written backward kernels (the reference differentiates through the
+unrolled Sinkhorn loop with tf.GradientTape, kernel_train.py:221,252,262,289).
+
+There is no CPU path: tensors must live on the GPU and the library must be built.
+"""
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_of, workspace
+
+__all__ = ["cost_xy", "modified_cost", "bi_causal_modified_cost", "benchmark_sinkhorn",
+           "compute_sinkhorn", "compute_N", "scale_invariante_martingale_regularization",
+           "compute_sinkhorn_loss", "last_info"]
+
+# executed Sinkhorn iteration counts (device int32 tensors, no host sync) of the latest calls;
+# the reference keeps them in a local (gan_utils.py:148,158) although its docstring promises them
+last_info = {}
+
+# cost-kernel selection for tests/bench: 0 = automatic, or _lib.COST_FORCE_DIRECT / _lib.COST_FORCE_MFMA
+cost_flags = 0
+
+_THRESH = 10 ** (-2)   # gan_utils.py:91,144
+_LMIN = 100            # gan_utils.py:149
+
+
+def _flat2(x):
+    """[B, ...] -> contiguous fp32 [B, K].  cost_xy sums over ALL trailing axes
+    (gan_utils.py:16-17), so any trailing shape -- including the un-transposed [B,H,T,W,C]
+    video (gan_utils.py:217-220) -- is just a row of K numbers."""
+    if x.dim() < 2:
+        raise ValueError("expected [batch, ...], got shape %s" % (tuple(x.shape),))
+    _lib.require_gpu(x)
+    x = x.reshape(x.shape[0], -1)
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.contiguous()
+
+
+def _feat(t):
+    if t.dim() != 3:
+        raise ValueError("h / M must be [batch, time steps, J], got %s" % (tuple(t.shape),))
+    _lib.require_gpu(t)
+    t = t if t.dtype == torch.float32 else t.float()
+    return t.contiguous()
+
+
+def _same(x, y):
+    return x.data_ptr() == y.data_ptr() and x.shape == y.shape
+
+
+class _PairwiseCost(torch.autograd.Function):
+    """C = cost_xy(x, y) [+ causal(h1, M1)] [+ causal(h2, M2)]   (gan_utils.py:6-72)"""
+
+    @staticmethod
+    def forward(ctx, x, y, h1, M1, h2, M2, sc):
+        Bx, K = x.shape
+        By = y.shape[0]
+        if y.shape[1] != K:
+            raise ValueError("x and y disagree on the feature count: %d vs %d" % (K, y.shape[1]))
+        T = J = 1
+        for h, M in ((h1, M1), (h2, M2)):
+            if h is not None:
+                if h.shape[0] != Bx or M.shape[0] != By or h.shape[1:] != M.shape[1:]:
+                    raise ValueError("h must be [Bx,T,J] and M [By,T,J]; got %s and %s"
+                                     % (tuple(h.shape), tuple(M.shape)))
+                T, J = h.shape[1], h.shape[2]
+        same = _same(x, y)
+        flags = (_lib.COST_SAME if same else 0) | cost_flags
+        C = torch.empty((Bx, By), dtype=torch.float32, device=x.device)
+        ws, wsb = workspace(lib.kccot_pairwise_cost_workspace_bytes(Bx, By, K), x)
+        check(lib.kccot_pairwise_cost_f32(ptr(x), ptr(y), Bx, By, K, sc, ptr(h1), ptr(M1), ptr(h2), ptr(M2),
+                                          T, J, flags, ptr(C), ws, wsb, stream_of(x)), "pairwise_cost")
+        ctx.save_for_backward(x, y, h1, M1, h2, M2)
+        ctx.sc, ctx.same, ctx.TJ = sc, same, (T, J)
+        return C
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, h1, M1, h2, M2 = ctx.saved_tensors
+        g = g.contiguous()
+        Bx, K = x.shape
+        By = y.shape[0]
+        T, J = ctx.TJ
+        need = ctx.needs_input_grad
+        want_x, want_y = need[0], need[1] and not ctx.same
+        if ctx.same:
+            want_x = need[0] or need[1]
+        dx = torch.empty_like(x) if want_x else None
+        dy = torch.empty_like(y) if want_y else None
+        dh1 = torch.empty_like(h1) if (h1 is not None and need[2]) else None
+        dM1 = torch.empty_like(M1) if (M1 is not None and need[3]) else None
+        dh2 = torch.empty_like(h2) if (h2 is not None and need[4]) else None
+        dM2 = torch.empty_like(M2) if (M2 is not None and need[5]) else None
+        flags = _lib.COST_SAME if ctx.same else 0
+        ws, wsb = workspace(lib.kccot_pairwise_cost_bwd_workspace_bytes(Bx, By), x)
+        st = stream_of(x)
+        if dx is not None or dy is not None or dh1 is not None or dM1 is not None:
+            check(lib.kccot_pairwise_cost_bwd_f32(ptr(g), ptr(x), ptr(y), Bx, By, K, ctx.sc, ptr(h1), ptr(M1), T, J,
+                                                  flags, ptr(dx), ptr(dy), ptr(dh1), ptr(dM1), ws, wsb, st),
+                  "pairwise_cost_bwd")
+        if dh2 is not None or dM2 is not None:
+            check(lib.kccot_pairwise_cost_bwd_f32(ptr(g), ptr(x), ptr(y), Bx, By, K, ctx.sc, ptr(h2), ptr(M2), T, J,
+                                                  flags, None, None, ptr(dh2), ptr(dM2), ws, wsb, st),
+                  "pairwise_cost_bwd")
+        if ctx.same:
+            # x and y are one tensor: its whole gradient is returned once (autograd would add the two)
+            return (dx if need[0] else None), (dx if (need[1] and not need[0]) else None), dh1, dM1, dh2, dM2, None
+        return dx, dy, dh1, dM1, dh2, dM2, None
+
+
+class _Cost3(torch.autograd.Function):
+    """The three cost matrices of compute_sinkhorn_loss (gan_utils.py:221-223), one pass over the videos."""
+
+    @staticmethod
+    def forward(ctx, real, fake, h_fake, h_real, m_real, m_fake, sc):
+        B, K = real.shape
+        if fake.shape != real.shape:
+            raise ValueError("real and fake must have the same shape: %s vs %s" % (tuple(real.shape), tuple(fake.shape)))
+        T, J = h_fake.shape[1], h_fake.shape[2]
+        for t in (h_fake, h_real, m_real, m_fake):
+            if tuple(t.shape) != (B, T, J):
+                raise ValueError("h / M must all be [%d,%d,%d]; got %s" % (B, T, J, tuple(t.shape)))
+        C3 = torch.empty((3, B, B), dtype=torch.float32, device=real.device)
+        ws, wsb = workspace(lib.kccot_pairwise_cost3_workspace_bytes(B, K), real)
+        check(lib.kccot_pairwise_cost3_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
+                                           ptr(m_fake), T, J, cost_flags, ptr(C3), ws, wsb, stream_of(real)),
+              "pairwise_cost3")
+        ctx.save_for_backward(real, fake, h_fake, h_real, m_real, m_fake)
+        ctx.sc = sc
+        return C3
+
+    @staticmethod
+    def backward(ctx, g3):
+        real, fake, h_fake, h_real, m_real, m_fake = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("the loss path never differentiates w.r.t. real (kernel_train.py:252,289); "
+                                      "use compute_sinkhorn for a gradient w.r.t. both operands")
+        g3 = g3.contiguous()
+        B, K = real.shape
+        T, J = h_fake.shape[1], h_fake.shape[2]
+        need = ctx.needs_input_grad
+        dfake = torch.empty_like(fake) if need[1] else None
+        dhf = torch.empty_like(h_fake) if need[2] else None
+        dhr = torch.empty_like(h_real) if need[3] else None
+        dmr = torch.empty_like(m_real) if need[4] else None
+        dmf = torch.empty_like(m_fake) if need[5] else None
+        ws, wsb = workspace(lib.kccot_pairwise_cost3_bwd_workspace_bytes(B, K), real)
+        check(lib.kccot_pairwise_cost3_bwd_f32(ptr(g3), ptr(real), ptr(fake), B, K, ctx.sc, ptr(h_fake), ptr(h_real),
+                                               ptr(m_real), ptr(m_fake), T, J, ptr(dfake), ptr(dhf), ptr(dhr),
+                                               ptr(dmr), ptr(dmf), ws, wsb, stream_of(real)), "pairwise_cost3_bwd")
+        return None, dfake, dhf, dhr, dmr, dmf, None
+
+
+class _Sinkhorn(torch.autograd.Function):
+    """cost[p] = sum(pi_p * C_p) after the Sinkhorn loop on C [nprob,n,n] (gan_utils.py:138-165)."""
+
+    @staticmethod
+    def forward(ctx, C, eps, L, Lmin, stop_mode, tag):
+        nprob, n, _ = C.shape
+        C = C.contiguous()
+        dev = C.device
+        keep = ctx.needs_input_grad[0]
+        Lh = max(int(L), 1)
+        u_hist = torch.empty((nprob, Lh, n), dtype=torch.float32, device=dev) if keep else None
+        v_hist = torch.empty((nprob, Lh, n), dtype=torch.float32, device=dev) if keep else None
+        cost = torch.empty((nprob,), dtype=torch.float32, device=dev)
+        nits = torch.empty((nprob,), dtype=torch.int32, device=dev)
+        check(lib.kccot_sinkhorn_fwd_f32(ptr(C), nprob, n, float(eps), int(L), int(Lmin), _THRESH, stop_mode,
+                                         ptr(u_hist), ptr(v_hist), ptr(cost), ptr(nits), None, None, 0,
+                                         stream_of(C)), "sinkhorn_fwd")
+        last_info[tag] = nits
+        if keep:
+            ctx.save_for_backward(C, u_hist, v_hist, nits)
+        ctx.eps, ctx.Lh = float(eps), Lh
+        return cost
+
+    @staticmethod
+    def backward(ctx, gcost):
+        C, u_hist, v_hist, nits = ctx.saved_tensors
+        nprob, n, _ = C.shape
+        gcost = gcost.contiguous().float()
+        dC = torch.empty_like(C)
+        check(lib.kccot_sinkhorn_bwd_f32(ptr(C), ptr(u_hist), ptr(v_hist), ptr(nits), nprob, n, ctx.eps, ctx.Lh,
+                                         ptr(gcost), ptr(dC), None, 0, stream_of(C)), "sinkhorn_bwd")
+        return dC, None, None, None, None, None
+
+
+class _Martingale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, M, lam, sc):
+        B, T, J = M.shape
+        pm = torch.empty((1,), dtype=torch.float32, device=M.device)
+        check(lib.kccot_martingale_fwd_f32(ptr(M), B, T, J, lam, sc, ptr(pm), stream_of(M)), "martingale_fwd")
+        ctx.save_for_backward(M)
+        ctx.lam, ctx.sc = lam, sc
+        return pm.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (M,) = ctx.saved_tensors
+        B, T, J = M.shape
+        g = g.reshape(1).contiguous().float()
+        dM = torch.empty_like(M)
+        check(lib.kccot_martingale_bwd_f32(ptr(M), B, T, J, ctx.lam, ctx.sc, ptr(g), ptr(dM), stream_of(M)),
+              "martingale_bwd")
+        return dM, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's public functions
+# ------------------------------------------------------------------------------------------------
+def cost_xy(x, y, scaling_coef):
+    """gan_utils.py:6-18.  x, y: [batch, time steps, features] -> [batch_x, batch_y] matrix of
+    scaling_coef * squared L2 distance summed over time and features."""
+    return _PairwiseCost.apply(_flat2(x), _flat2(y), None, None, None, None, float(scaling_coef))
+
+
+def modified_cost(x, y, h, M, scaling_coef):
+    """gan_utils.py:21-43.  cost_xy + scaling_coef * sum_{t<T-1} h[i,t]*(M[j,t+1]-M[j,t]):
+    h indexes rows, M indexes columns (gan_utils.py:37)."""
+    return _PairwiseCost.apply(_flat2(x), _flat2(y), _feat(h), _feat(M), None, None, float(scaling_coef))
+
+
+def bi_causal_modified_cost(x, y, hy, Mx, hx, My, scaling_coef):
+    """gan_utils.py:46-72.  cost_xy + C_hM(hy, Mx) + C_Mh(hx, My)."""
+    return _PairwiseCost.apply(_flat2(x), _flat2(y), _feat(hy), _feat(Mx), _feat(hx), _feat(My),
+                               float(scaling_coef))
+
+
+def _solve(C, epsilon, L, Lmin, stop_mode, tag):
+    return _Sinkhorn.apply(C.unsqueeze(0), float(epsilon), int(L), int(Lmin), stop_mode, tag)[0]
+
+
+def benchmark_sinkhorn(x, y, scaling_coef, epsilon=1.0, L=10, Lmin=10):
+    """gan_utils.py:75-121.  Sinkhorn on the plain cost_xy; the stop rule tests the loop INDEX
+    against Lmin (gan_utils.py:116)."""
+    return _solve(cost_xy(x, y, scaling_coef), epsilon, L, Lmin, _lib.STOP_INDEX, "benchmark_sinkhorn")
+
+
+def compute_sinkhorn(x, y, hy, Mx, scaling_coef, hx=None, My=None, epsilon=1.0, L=100, bi_causal=False):
+    """gan_utils.py:124-165.  Lmin = 100 is hard-coded in the reference (gan_utils.py:149)."""
+    if bi_causal:
+        C = bi_causal_modified_cost(x, y, hy, Mx, hx, My, scaling_coef)
+    else:
+        C = modified_cost(x, y, hy, Mx, scaling_coef)
+    return _solve(C, epsilon, L, _LMIN, _lib.STOP_COUNT, "compute_sinkhorn")
+
+
+def compute_N(M):
+    """gan_utils.py:168-176 (unused by the reference's training loop)."""
+    T = M.shape[1]
+    return M[:, 1:] - M[:, :T - 1]
+
+
+def scale_invariante_martingale_regularization(M, reg_lam, scaling_coef):
+    """gan_utils.py:179-201."""
+    return _Martingale.apply(_feat(M), float(reg_lam), float(scaling_coef))
+
+
+def compute_sinkhorn_loss(f_real, f_fake, scaling_coef, sinkhorn_eps, sinkhorn_l, h_fake, m_real, h_real,
+                          m_fake, video=True, *, honor_eps_l=False):
+    """gan_utils.py:204-227: 2*W(real,fake) - W(real,real) - W(fake,fake).
+
+    As in the reference, ``sinkhorn_eps`` and ``sinkhorn_l`` are accepted and IGNORED: the
+    reference passes them positionally into the ``hx`` / ``My`` slots of ``compute_sinkhorn``
+    (gan_utils.py:221-223 vs :124), which are unused when bi_causal=False, so the loss always
+    runs with epsilon = 1.0 and L = 100.  ``honor_eps_l=True`` (keyword-only, not in the
+    reference) opts into the documented intent instead.
+
+    ``video=True`` inputs are [B,H,T,W,C]; the reference's transpose(0,2,1,3,4)+reshape
+    (gan_utils.py:217-220) does not change a sum over all of (T,H,W,C), so the buffer is read as is.
+    """
+    del video  # both layouts flatten to [B, K]
+    eps, L = (float(sinkhorn_eps), int(sinkhorn_l)) if honor_eps_l else (1.0, 100)
+    real, fake = _flat2(f_real), _flat2(f_fake)
+    C3 = _Cost3.apply(real, fake, _feat(h_fake), _feat(h_real), _feat(m_real), _feat(m_fake), float(scaling_coef))
+    w = _Sinkhorn.apply(C3, eps, L, _LMIN, _lib.STOP_COUNT, "compute_sinkhorn_loss")   # [xy, xx, yy]
+    return 2.0 * w[0] - w[1] - w[2]

@@ -1,0 +1,105 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol that
+include/kccot.h declares, rejects bad arguments before any launch, and the Python host mirror keeps
+the reference's signatures.  No compute call is made (no GPU here)."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "kccot.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kccot_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from kccotgan_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(_lib.lib, s), "libkccot.so does not export %s" % s
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
+    assert _lib.lib.kccot_version() == 100
+
+
+def test_argument_validation_happens_before_any_launch():
+    from kccotgan_amd import _lib
+    lib = _lib.lib
+    one = ctypes.c_void_p(16)   # never dereferenced: every call below is rejected on its arguments
+    assert lib.kccot_pairwise_cost_f32(None, one, 4, 4, 8, 1.0, None, None, None, None, 1, 1, 0, one, None, 0, None) == _lib.EINVAL
+    assert b"null" in lib.kccot_last_error()
+    assert lib.kccot_pairwise_cost_f32(one, one, 0, 4, 8, 1.0, None, None, None, None, 1, 1, 0, one, None, 0, None) == _lib.EINVAL
+    assert lib.kccot_pairwise_cost_f32(one, one, 4, 4, 8, 1.0, one, None, None, None, 2, 2, 0, one, None, 0, None) == _lib.EINVAL
+    # workspace too small is reported, not overrun
+    need = lib.kccot_pairwise_cost_workspace_bytes(4, 4, 64)
+    assert need > 0
+    assert lib.kccot_pairwise_cost_f32(one, one, 4, 4, 64, 1.0, None, None, None, None, 1, 1, 0, one, one, 16, None) == _lib.EWORKSPACE
+    assert lib.kccot_sinkhorn_fwd_f32(one, 1, 0, 1.0, 10, 10, 0.01, 0, None, None, one, one, None, None, 0, None) == _lib.EINVAL
+    assert lib.kccot_sinkhorn_fwd_f32(one, 1, 8, -1.0, 10, 10, 0.01, 0, None, None, one, one, None, None, 0, None) == _lib.EINVAL
+    assert lib.kccot_sinkhorn_fwd_f32(one, 1, 4096, 1.0, 10, 10, 0.01, 0, None, None, one, one, None, None, 0, None) == _lib.EUNSUPPORTED
+    assert lib.kccot_smooth_fwd_f32(one, 2, 8, 3, 8, 1, 5.0, 3, _lib.SMOOTH_T, one, one, one, 1 << 30, None) == _lib.EINVAL  # radius >= T
+    assert lib.kccot_martingale_fwd_f32(one, 0, 4, 4, 1.0, 1.0, one, None) == _lib.EINVAL
+
+
+def test_workspace_queries_are_monotone_and_cover_both_cost_paths():
+    from kccotgan_amd import _lib
+    lib = _lib.lib
+    a = lib.kccot_pairwise_cost3_workspace_bytes(64, 122880)
+    b = lib.kccot_pairwise_cost3_workspace_bytes(64, 2 * 122880)
+    assert 0 < a <= b
+    assert lib.kccot_pairwise_cost3_workspace_bytes(0, 10) == 0
+    assert lib.kccot_smooth_workspace_bytes(2, 8, 4, 8, 1) >= 2 * 8 * 4 * 8 * 4
+
+
+def test_host_mirror_keeps_reference_signatures():
+    """Names, argument order and defaults of gan_utils.py:6,21,46,75,124,168,179,204 and
+    data_utils.py:479,503,523,552,584."""
+    from kccotgan_amd import gan_utils as g, data_utils as d
+
+    def params(f):
+        return [(p.name, p.default if p.default is not inspect._empty else None)
+                for p in inspect.signature(f).parameters.values() if p.kind != p.KEYWORD_ONLY]
+
+    assert params(g.cost_xy) == [("x", None), ("y", None), ("scaling_coef", None)]
+    assert params(g.modified_cost) == [("x", None), ("y", None), ("h", None), ("M", None), ("scaling_coef", None)]
+    assert [n for n, _ in params(g.bi_causal_modified_cost)] == ["x", "y", "hy", "Mx", "hx", "My", "scaling_coef"]
+    assert params(g.benchmark_sinkhorn) == [("x", None), ("y", None), ("scaling_coef", None), ("epsilon", 1.0),
+                                            ("L", 10), ("Lmin", 10)]
+    assert params(g.compute_sinkhorn) == [("x", None), ("y", None), ("hy", None), ("Mx", None),
+                                          ("scaling_coef", None), ("hx", None), ("My", None), ("epsilon", 1.0),
+                                          ("L", 100), ("bi_causal", False)]
+    assert [n for n, _ in params(g.compute_sinkhorn_loss)] == [
+        "f_real", "f_fake", "scaling_coef", "sinkhorn_eps", "sinkhorn_l", "h_fake", "m_real", "h_real",
+        "m_fake", "video"]
+    assert params(g.scale_invariante_martingale_regularization) == [("M", None), ("reg_lam", None),
+                                                                    ("scaling_coef", None)]
+    assert params(g.compute_N) == [("M", None)]
+    ks = d.KernelSmoothing()
+    assert (ks.temporal_radius, ks.spatial_radius) == (3, 4)            # data_utils.py:479-481 defaults 6, 8
+    ks = d.KernelSmoothing(temporal_kernel_size=6, spatial_kernel_size=6)   # kernel_train.py:216
+    assert (ks.temporal_radius, ks.spatial_radius) == (3, 3)
+    assert params(ks.annealing_sigma) == [("init_sigma", None), ("step", None), ("decay_steps", 500),
+                                          ("decay_rate", 0.975)]
+    assert abs(ks.annealing_sigma(5.0, 1000) - 5.0 * 0.975 ** 2) < 1e-12
+    for m in ("temporal_convolution", "spatial_convolution", "gaussian_convolution3D"):
+        assert [n for n, _ in params(getattr(ks, m))] == ["inputs", "sigma"]
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a GPU tensor -- never route through the oracle."""
+    import torch
+    from kccotgan_amd import gan_utils as g, _lib
+    x = torch.zeros(2, 3, 4)
+    with pytest.raises(_lib.KccotError):
+        g.cost_xy(x, x, 1.0)
+    src = ""
+    for root, _, files in os.walk(os.path.join(ROOT, "kccotgan_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src += open(os.path.join(root, f)).read()
+    assert "import oracle" not in src and "from oracle" not in src

@@ -1,0 +1,367 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (ctypes -> libkccot.so), against
+  (1) the golden vectors produced by the reference's own gan_utils.py (tests/golden),
+  (2) the CPU oracle on the same seeded inputs,
+  (3) size-independent properties at BASELINE configs[1] full size.
+
+Tolerances (fp32 path; BASELINE.json north_star: loss within 1e-4 relative of the reference):
+  cost matrices     : 1e-5 * max|C|            (reference fp32 vs our fp32/fp64-combine)
+  Sinkhorn costs    : 5e-5 relative to the fp32 golden value, 1e-4 to the fp64 one
+  final loss        : 1e-4 relative (the stated target), against BOTH golden values
+  iteration counts  : identical
+  gradients         : 2e-3 * max|grad| against fp64 autograd through the unrolled loop
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import gan_utils_np as o
+from oracle import gan_utils_torch as ot
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+ALL = cases.CASES
+SMALL = [c for c in cases.CASES if c[0] != "cfg2"]
+
+
+@pytest.fixture(scope="module")
+def G():
+    from kccotgan_amd import gan_utils
+    return gan_utils
+
+
+@pytest.fixture(scope="module")
+def L():
+    from kccotgan_amd import _lib
+    return _lib
+
+
+def load(shape, seed, regime):
+    g = np.load(os.path.join(GOLD, cases.case_name(shape, seed, regime) + ".npz"))
+    inp = cases.gen_inputs(shape, seed, regime)
+    np.testing.assert_array_equal(cases.checksum(inp), g["checksum"])
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+    return g, inp, t
+
+
+def rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
+
+
+def flat(v):
+    return v.permute(0, 2, 1, 3, 4).reshape(v.shape[0], v.shape[2], -1).contiguous()
+
+
+PATHS = ["auto", "direct", "mfma"]
+
+
+def set_path(G, L, path):
+    G.cost_flags = {"auto": 0, "direct": L.COST_FORCE_DIRECT, "mfma": L.COST_FORCE_MFMA}[path]
+
+
+@pytest.fixture(autouse=True)
+def _reset_flags(G):
+    yield
+    G.cost_flags = 0
+
+
+# ---------------------------------------------------------------- cost matrices
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("shape,seed,regime", ALL)
+def test_cost3_matches_reference(G, L, shape, seed, regime, path):
+    g, inp, t = load(shape, seed, regime)
+    set_path(G, L, path)
+    B = t["real"].shape[0]
+    real, fake = t["real"].reshape(B, -1), t["fake"].reshape(B, -1)
+    C3 = G._Cost3.apply(real, fake, t["h_fake"], t["h_real"], t["m_real"], t["m_fake"], cases.SC).cpu().numpy()
+    for k, tag in enumerate(("xy", "xx", "yy")):
+        ref = g["C_" + tag]
+        np.testing.assert_allclose(C3[k], ref, rtol=0, atol=1e-5 * np.abs(ref).max(), err_msg=tag)
+        ref64 = g["C_" + tag + "_f64"]
+        np.testing.assert_allclose(C3[k], ref64, rtol=0, atol=1e-5 * np.abs(ref64).max(), err_msg=tag + " f64")
+    # x == y problems: the l2 part of the diagonal is exactly 0, as (x-x)^2 in the reference
+    caus = o.causal_term(inp["h_real"], inp["m_real"], cases.SC)
+    np.testing.assert_allclose(np.diag(C3[1]), np.diag(caus), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("shape,seed,regime", SMALL)
+def test_public_cost_functions(G, L, shape, seed, regime, path):
+    g, inp, t = load(shape, seed, regime)
+    set_path(G, L, path)
+    x, y = flat(t["real"]), flat(t["fake"])
+    tol = lambda ref: dict(rtol=0, atol=1e-5 * np.abs(ref).max())
+    np.testing.assert_allclose(G.cost_xy(x, y, cases.SC).cpu().numpy(), g["C_plain"], **tol(g["C_plain"]))
+    np.testing.assert_allclose(G.modified_cost(x, y, t["h_fake"], t["m_real"], cases.SC).cpu().numpy(),
+                               g["C_xy"], **tol(g["C_xy"]))
+    np.testing.assert_allclose(
+        G.bi_causal_modified_cost(x, y, t["h_fake"], t["m_real"], t["h_real"], t["m_fake"], cases.SC).cpu().numpy(),
+        g["C_bicausal"], **tol(g["C_bicausal"]))
+    Cxx = G.cost_xy(x, x, cases.SC).cpu().numpy()
+    assert np.all(np.diag(Cxx) == 0) and np.array_equal(Cxx, Cxx.T)
+    np.testing.assert_array_equal(G.compute_N(t["m_real"]).cpu().numpy(), g["N_m_real"])
+
+
+def test_cost_ragged_shapes_and_unaligned_k(G, L):
+    """Bx != By, K not a multiple of 4 (scalar tail path), more than one 64-row tile."""
+    rng = np.random.default_rng(11)
+    for Bx, By, K in ((3, 7, 13), (70, 5, 37), (130, 67, 96), (1, 1, 1)):
+        x = rng.random((Bx, K), dtype=np.float32)
+        y = rng.random((By, K), dtype=np.float32)
+        ref = o.cost_xy(x[:, None, :], y[:, None, :], 0.5, dtype=np.float64)
+        got = G.cost_xy(torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV), 0.5).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-6)
+    x = rng.random((130, 52), dtype=np.float32)   # x == y across tiles: mirrored lower triangle
+    xt = torch.from_numpy(x).to(DEV)
+    got = G.cost_xy(xt, xt, 1.0).cpu().numpy()
+    np.testing.assert_allclose(got, o.cost_xy(x[:, None], x[:, None], 1.0, dtype=np.float64), rtol=2e-6, atol=1e-6)
+    assert np.all(np.diag(got) == 0) and np.array_equal(got, got.T)
+
+
+# ---------------------------------------------------------------- Sinkhorn
+@pytest.mark.parametrize("shape,seed,regime", SMALL)
+def test_sinkhorn_variants_match_reference(G, shape, seed, regime):
+    g, inp, t = load(shape, seed, regime)
+    x, y = flat(t["real"]), flat(t["fake"])
+    for eps, Lc in cases.EPS_L:
+        key = "e%g_L%d" % (eps, Lc)
+        w = G.compute_sinkhorn(x, y, t["h_fake"], t["m_real"], cases.SC, epsilon=eps, L=Lc)
+        assert int(G.last_info["compute_sinkhorn"][0]) == int(g["nits_" + key]), key
+        assert rel(w, g["w_" + key]) < 5e-5, key
+        assert rel(w, g["w_" + key + "_f64"]) < 1e-4, key
+    w = G.compute_sinkhorn(x, y, t["h_fake"], t["m_real"], cases.SC, hx=t["h_real"], My=t["m_fake"], bi_causal=True)
+    assert rel(w, g["w_bicausal"]) < 5e-5 and int(G.last_info["compute_sinkhorn"][0]) == int(g["nits_bicausal"])
+    w = G.benchmark_sinkhorn(x, y, cases.SC)
+    assert rel(w, g["w_bench_default"]) < 5e-5 and int(G.last_info["benchmark_sinkhorn"][0]) == 10
+    w = G.benchmark_sinkhorn(x, y, cases.SC, epsilon=0.8, L=50, Lmin=20)
+    assert rel(w, g["w_bench_e0.8_L50_Lmin20"]) < 5e-5
+    assert int(G.last_info["benchmark_sinkhorn"][0]) == int(g["nits_bench_e0.8_L50_Lmin20"])
+
+
+def test_sinkhorn_stop_rule_past_lmin(G):
+    """Quirk 2 (gan_utils.py:149-160): L <= 100 runs exactly L; beyond, the loop stops at the
+    first iteration >= 100 with sum|u-u_prev| < 1e-2 -- 198 on this crafted problem."""
+    g = np.load(os.path.join(GOLD, "line32.npz"))
+    x, y, h, M = (torch.from_numpy(a).to(DEV) for a in cases.gen_line_inputs())
+    for sc, Lc in cases.LINE_RUNS:
+        key = "sc%g_L%d" % (sc, Lc)
+        w = G.compute_sinkhorn(x, y, h, M, sc, L=Lc)
+        assert int(G.last_info["compute_sinkhorn"][0]) == int(g["nits_" + key]), key
+        assert rel(w, g["w_" + key]) < 1e-4, key
+
+
+def test_sinkhorn_kats(G, L):
+    from kccotgan_amd._lib import lib, ptr
+    for n in (1, 2, 7, 33, 64, 100, 128):
+        C = torch.full((1, n, n), 2.5, device=DEV)
+        cost = G._Sinkhorn.apply(C, 1.0, 100, 100, L.STOP_COUNT, "kat")
+        assert abs(float(cost[0]) - 2.5) < 2e-5, n          # constant C -> uniform plan -> cost = C
+    # column marginals equal 1/n after the v-update (update order: u, then v with the new u)
+    n = 9
+    Cn = np.random.default_rng(0).random((n, n), dtype=np.float32) * 3
+    C = torch.from_numpy(Cn).to(DEV).reshape(1, n, n)
+    cost = torch.empty(1, device=DEV)
+    nits = torch.empty(1, dtype=torch.int32, device=DEV)
+    pi = torch.empty(1, n, n, device=DEV)
+    rc = lib.kccot_sinkhorn_fwd_f32(ptr(C), 1, n, 0.7, 13, 100, 1e-2, 0, None, None, ptr(cost), ptr(nits), ptr(pi),
+                                    None, 0, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pi[0].sum(0).cpu().numpy(), 1 / n, rtol=3e-6)
+    ref = o.sinkhorn_from_cost(Cn, 0.7, 13)
+    assert int(nits[0]) == 13 and rel(cost[0], ref[0]) < 1e-5
+    np.testing.assert_allclose(pi[0].cpu().numpy(), ref[4], rtol=1e-4, atol=1e-7)
+    # several problems per launch, sizes that do not fill the thread grid
+    for n in (5, 48, 100):
+        Cn = np.random.default_rng(n).random((3, n, n), dtype=np.float32) * 4
+        got = G._Sinkhorn.apply(torch.from_numpy(Cn).to(DEV), 0.5, 37, 100, L.STOP_COUNT, "kat").cpu().numpy()
+        for p in range(3):
+            assert rel(got[p], o.sinkhorn_from_cost(Cn[p], 0.5, 37)[0]) < 2e-5, (n, p)
+
+
+# ---------------------------------------------------------------- the loss
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("shape,seed,regime", ALL)
+def test_loss_matches_reference(G, L, shape, seed, regime, path):
+    g, inp, t = load(shape, seed, regime)
+    set_path(G, L, path)
+    loss = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 100, t["h_fake"], t["m_real"],
+                                   t["h_real"], t["m_fake"], video=True)
+    nits = G.last_info["compute_sinkhorn_loss"].cpu().numpy().tolist()
+    assert nits == [int(g["nits_xy"]), int(g["nits_xx"]), int(g["nits_yy"])]
+    assert rel(loss, g["loss"]) < 1e-4 and rel(loss, g["loss_f64"]) < 1e-4
+    # quirk 1 (gan_utils.py:221-223): the eps / L arguments are ignored
+    loss2 = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.1, 5, t["h_fake"], t["m_real"],
+                                    t["h_real"], t["m_fake"])
+    assert float(loss2) == float(loss)
+    pm = G.scale_invariante_martingale_regularization(t["m_real"], cases.LAM, cases.SC)
+    assert rel(pm, g["pM"]) < 2e-5
+
+
+def test_loss_honor_eps_l_opt_in(G):
+    g, inp, t = load("small", 1, "far")
+    x, y = flat(t["real"]), flat(t["fake"])
+    got = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 20, t["h_fake"], t["m_real"], t["h_real"],
+                                  t["m_fake"], honor_eps_l=True)
+    xy = G.compute_sinkhorn(x, y, t["h_fake"], t["m_real"], cases.SC, epsilon=0.8, L=20)
+    xx = G.compute_sinkhorn(x, x, t["h_real"], t["m_real"], cases.SC, epsilon=0.8, L=20)
+    yy = G.compute_sinkhorn(y, y, t["h_fake"], t["m_fake"], cases.SC, epsilon=0.8, L=20)
+    assert rel(got, 2 * xy - xx - yy) < 1e-5
+    assert rel(xy, g["w_e0.8_L20"]) < 5e-5
+
+
+def test_very_near_regime_keeps_relative_accuracy(G, L):
+    """fake within 0.5% of real (late training / after smoothing): distances are 1e-4 of the
+    norms, the regime where a plain Gram form loses everything.  Both paths must hold 1e-4."""
+    B, H, T, W, C, J = cases.SHAPES["cfg1"]
+    rng = np.random.default_rng(7)
+    real = rng.random((B, H, T, W, C), dtype=np.float32)
+    fake = np.clip(real + np.float32(0.005) * rng.standard_normal(real.shape, dtype=np.float32), 0, 1).astype(np.float32)
+    f = {k: rng.random((B, T, J), dtype=np.float32) * np.float32(0.01) for k in ("hf", "mr", "hr", "mf")}
+    ref = o.compute_sinkhorn_loss(real, fake, cases.SC, 0, 0, f["hf"], f["mr"], f["hr"], f["mf"], dtype=np.float64)
+    tt = lambda a: torch.from_numpy(a).to(DEV)
+    for path in PATHS:
+        set_path(G, L, path)
+        got = G.compute_sinkhorn_loss(tt(real), tt(fake), cases.SC, 0, 0, tt(f["hf"]), tt(f["mr"]), tt(f["hr"]), tt(f["mf"]))
+        assert rel(got, ref) < 1e-4, (path, float(got), float(ref))
+
+
+# ---------------------------------------------------------------- properties at full size (configs[1])
+def test_full_size_properties(G, L):
+    g, inp, t = load("cfg2", 0, "near")
+    B = t["real"].shape[0]
+    args = lambda r, f, hf, mr, hr, mf: (r, f, cases.SC, 0.8, 100, hf, mr, hr, mf)
+    base = G.compute_sinkhorn_loss(*args(t["real"], t["fake"], t["h_fake"], t["m_real"], t["h_real"], t["m_fake"]))
+    # batch-permutation invariance (the property that makes batch sharding legal)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
+    p = lambda a: a[perm].contiguous()
+    permuted = G.compute_sinkhorn_loss(*args(p(t["real"]), p(t["fake"]), p(t["h_fake"]), p(t["m_real"]),
+                                             p(t["h_real"]), p(t["m_fake"])))
+    assert rel(permuted, base) < 2e-5
+    # translation invariance of the l2 cost, linearity in scaling_coef, zero diagonal / symmetry
+    x, y = t["real"].reshape(B, -1), t["fake"].reshape(B, -1)
+    for path in ("direct", "mfma"):
+        set_path(G, L, path)
+        C = G.cost_xy(x, y, cases.SC)
+        C2 = G.cost_xy(x, y, 2 * cases.SC)
+        assert float((C2 - 2 * C).abs().max()) <= 2e-6 * float(C.abs().max())
+        Cs = G.cost_xy(x + 0.25, y + 0.25, cases.SC)
+        assert float((Cs - C).abs().max()) <= 2e-5 * float(C.abs().max())
+        Cxx = G.cost_xy(x, x, cases.SC)
+        assert float(Cxx.diagonal().abs().max()) == 0 and torch.equal(Cxx, Cxx.t())
+    set_path(G, L, "auto")
+    # plan is a coupling: feed the golden cost matrix, check both marginals and the cost
+    from kccotgan_amd._lib import lib, ptr
+    C = torch.from_numpy(g["C_xy"]).to(DEV).reshape(1, B, B).contiguous()
+    cost = torch.empty(1, device=DEV); nits = torch.empty(1, dtype=torch.int32, device=DEV); pi = torch.empty(1, B, B, device=DEV)
+    assert lib.kccot_sinkhorn_fwd_f32(ptr(C), 1, B, 1.0, 100, 100, 1e-2, 0, None, None, ptr(cost), ptr(nits), ptr(pi),
+                                      None, 0, None) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pi[0].sum(0).cpu().numpy(), 1 / B, rtol=1e-5)
+    np.testing.assert_allclose(pi[0].sum(1).cpu().numpy(), 1 / B, rtol=1e-3)
+    assert rel(cost[0], g["w_xy"]) < 5e-5
+
+
+# ---------------------------------------------------------------- gradients
+def _grad_oracle(inp, wrt, fn):
+    t = {k: torch.from_numpy(v).double() for k, v in inp.items()}
+    for k in wrt:
+        t[k].requires_grad_(True)
+    val = fn(t)
+    grads = torch.autograd.grad(val, [t[k] for k in wrt])
+    return float(val), {k: gk.numpy() for k, gk in zip(wrt, grads)}
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("shape,seed,regime", [("tiny", 0, "near"), ("tiny", 1, "far"), ("small", 0, "near"),
+                                               ("small", 1, "far"), ("deci64", 0, "near"), ("deci64", 1, "far")])
+def test_loss_gradients_match_autograd_through_the_unrolled_loop(G, L, shape, seed, regime, path):
+    g, inp, t = load(shape, seed, regime)
+    set_path(G, L, path)
+    wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]     # kernel_train.py:252,289 (never real)
+    ref_val, ref = _grad_oracle(inp, wrt, lambda d: ot.compute_sinkhorn_loss(
+        d["real"], d["fake"], cases.SC, 0.8, 100, d["h_fake"], d["m_real"], d["h_real"], d["m_fake"]))
+    for k in wrt:
+        t[k].requires_grad_(True)
+    loss = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"],
+                                   t["m_fake"])
+    grads = torch.autograd.grad(loss, [t[k] for k in wrt])
+    assert rel(loss, ref_val) < 1e-4
+    for k, gk in zip(wrt, grads):
+        gk = gk.cpu().numpy()
+        scale = np.abs(ref[k]).max()
+        np.testing.assert_allclose(gk, ref[k], rtol=0, atol=2e-3 * scale, err_msg=k)
+
+
+def test_general_cost_and_sinkhorn_gradients(G):
+    """compute_sinkhorn (both operands differentiable, bi-causal) and the martingale penalty."""
+    g, inp, t = load("small", 1, "far")
+    wrt = ["real", "fake", "h_fake", "m_real", "h_real", "m_fake"]
+
+    def fn(d):
+        x, y = ot.flatten_video(d["real"]), ot.flatten_video(d["fake"])
+        return (ot.compute_sinkhorn(x, y, d["h_fake"], d["m_real"], cases.SC, hx=d["h_real"], My=d["m_fake"],
+                                    epsilon=0.8, L=30, bi_causal=True)
+                + ot.compute_sinkhorn(x, x, d["h_real"], d["m_real"], cases.SC, epsilon=0.8, L=30)
+                + 3.0 * ot.scale_invariante_martingale_regularization(d["m_real"], 1.5, cases.SC))
+
+    ref_val, ref = _grad_oracle(inp, wrt, fn)
+    for k in wrt:
+        t[k].requires_grad_(True)
+    x, y = flat(t["real"]), flat(t["fake"])
+    val = (G.compute_sinkhorn(x, y, t["h_fake"], t["m_real"], cases.SC, hx=t["h_real"], My=t["m_fake"], epsilon=0.8,
+                              L=30, bi_causal=True)
+           + G.compute_sinkhorn(x, x, t["h_real"], t["m_real"], cases.SC, epsilon=0.8, L=30)
+           + 3.0 * G.scale_invariante_martingale_regularization(t["m_real"], 1.5, cases.SC))
+    grads = torch.autograd.grad(val, [t[k] for k in wrt])
+    assert rel(val, ref_val) < 1e-4
+    for k, gk in zip(wrt, grads):
+        np.testing.assert_allclose(gk.cpu().numpy(), ref[k], rtol=0, atol=2e-3 * np.abs(ref[k]).max(), err_msg=k)
+
+
+def test_martingale_kats(G):
+    M = torch.rand(4, 1, 3, generator=torch.Generator().manual_seed(2)).repeat(1, 6, 1).to(DEV)
+    assert float(G.scale_invariante_martingale_regularization(M, 1.0, 0.5)) == 0      # constant in time
+    Mn = np.random.default_rng(9).random((6, 5, 4), dtype=np.float32)
+    got = G.scale_invariante_martingale_regularization(torch.from_numpy(Mn).to(DEV), 0.7, 0.3)
+    assert rel(got, o.scale_invariante_martingale_regularization(Mn, 0.7, 0.3, np.float64)) < 1e-5
+
+
+# ---------------------------------------------------------------- kernel smoothing
+@pytest.mark.parametrize("shape", [(2, 8, 9, 10, 1), (3, 16, 7, 12, 3), (2, 64, 20, 64, 1)])
+def test_smoothing_matches_oracle(shape):
+    from kccotgan_amd.data_utils import KernelSmoothing
+    from oracle import smoothing_np as sm
+    ks = KernelSmoothing(temporal_kernel_size=6, spatial_kernel_size=6)      # kernel_train.py:216
+    v = np.random.default_rng(shape[0]).random(shape, dtype=np.float32)
+    vt = torch.from_numpy(v).to(DEV)
+    for sigma in (5.0, 1.3):
+        np.testing.assert_allclose(ks.temporal_convolution(vt, sigma).cpu().numpy(),
+                                   sm.temporal_convolution(v, sigma), rtol=1e-5, atol=1e-6)
+        got = ks.gaussian_convolution3D(vt, sigma).cpu().numpy()
+        np.testing.assert_allclose(got, sm.gaussian_convolution3D_separable(v, sigma), rtol=1e-5, atol=1e-6)
+        assert float(got.max()) == 1.0
+        np.testing.assert_allclose(ks.spatial_convolution(vt, sigma).cpu().numpy(),
+                                   sm.spatial_convolution_reflect(v, sigma), rtol=1e-5, atol=1e-6)
+    if v.size < 20000:   # the literal dense 7x7x7 form of data_utils.py:552-582
+        np.testing.assert_allclose(ks.gaussian_convolution3D(vt, 2.0).cpu().numpy(),
+                                   sm.gaussian_convolution3D(v, 2.0), rtol=2e-5, atol=2e-6)
+    const = torch.full(shape, 0.37, device=DEV)
+    np.testing.assert_allclose(ks.gaussian_convolution3D(const, 5.0).cpu().numpy(), 1.0, rtol=1e-6)
+
+
+def test_smoothing_gradient_matches_autograd():
+    from kccotgan_amd.data_utils import KernelSmoothing
+    from oracle import smoothing_torch as st
+    ks = KernelSmoothing(6, 6)
+    v = np.random.default_rng(4).random((2, 8, 9, 10, 2), dtype=np.float32)
+    wgt = np.random.default_rng(5).standard_normal(v.shape).astype(np.float32)
+    for axes, fn in (((2,), ks.temporal_convolution), ((2, 1, 3), ks.gaussian_convolution3D)):
+        a = torch.from_numpy(v).double().requires_grad_(True)
+        (st.smooth(a, 2.0, 3, axes) * torch.from_numpy(wgt).double()).sum().backward()
+        b = torch.from_numpy(v).to(DEV).requires_grad_(True)
+        (fn(b, 2.0) * torch.from_numpy(wgt).to(DEV)).sum().backward()
+        np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.numpy(), rtol=0, atol=2e-4 * float(a.grad.abs().max()))

@@ -141,3 +141,26 @@ def test_kat_causal_orientation():
 def test_kat_martingale_constant_in_time_is_zero():
     M = np.repeat(np.random.default_rng(2).random((4, 1, 3), dtype=np.float32), 6, axis=1)
     assert o.scale_invariante_martingale_regularization(M, 1.0, 0.5) == 0
+
+
+# ---- the torch flavour of the oracle (gradient oracle + CPU-baseline code) against the same vectors ----
+
+@pytest.mark.parametrize("shape,seed,regime", [c for c in SMALL_CASES if c[0] in ("tiny", "small", "deci64")])
+def test_torch_oracle_matches_reference(shape, seed, regime):
+    import torch
+    from oracle import gan_utils_torch as ot
+    g, inp = load(shape, seed, regime)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    loss = ot.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 100, t["h_fake"], t["m_real"],
+                                    t["h_real"], t["m_fake"])
+    assert rel(loss, g["loss"]) < 2e-5
+    t64 = {k: v.double() for k, v in t.items()}
+    loss64 = ot.compute_sinkhorn_loss(t64["real"], t64["fake"], cases.SC, 0.8, 100, t64["h_fake"], t64["m_real"],
+                                      t64["h_real"], t64["m_fake"])
+    assert rel(loss64, g["loss_f64"]) < 1e-10
+    pm = ot.scale_invariante_martingale_regularization(t["m_real"], cases.LAM, cases.SC)
+    assert rel(pm, g["pM"]) < 1e-5
+    x, y = ot.flatten_video(t["real"]), ot.flatten_video(t["fake"])
+    w = ot.compute_sinkhorn(x, y, t["h_fake"], t["m_real"], cases.SC, hx=t["h_real"], My=t["m_fake"], bi_causal=True)
+    assert rel(w, g["w_bicausal"]) < 2e-5
+    assert rel(ot.benchmark_sinkhorn(x, y, cases.SC), g["w_bench_default"]) < 2e-5
