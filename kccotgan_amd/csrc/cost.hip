@@ -136,16 +136,16 @@ __global__ __launch_bounds__(256) void cost_direct_partial(CostBatch cb, int64_t
 // finalize: one thread per output element
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cost_finalize(CostBatch cb, int nchunk, float sc, int T, int J) {
-    const int p = blockIdx.y;
+    __shared__ float sh[CAUSAL_TILE * CAUSAL_PITCH], sm[CAUSAL_TILE * CAUSAL_PITCH];
+    const int p = blockIdx.z;
     const CostProb& pr = cb.p[p];
+    const int i0 = blockIdx.y * CAUSAL_TILE, j0 = blockIdx.x * CAUSAL_TILE;
+    if (i0 >= pr.Bx || j0 >= pr.By) return;   // block-uniform
+    const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
+    const bool ok = i < pr.Bx && j < pr.By;
     const int64_t n = (int64_t)pr.Bx * pr.By;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const int i = (int)(e / pr.By), j = (int)(e % pr.By);
-    float l2;
-    if (pr.same && i == j) {
-        l2 = 0.f;  // (x-x)^2 summed is exactly 0 in the reference (gan_utils.py:16)
-    } else {
+    float l2 = 0.f;
+    if (ok && !(pr.same && i == j)) {   // (x-x)^2 summed is exactly 0 in the reference (gan_utils.py:16)
         // x==y problems only computed tiles with tile_j >= tile_i
         const bool mirror = pr.same && (j / pr.tile) < (i / pr.tile);
         const int64_t off = mirror ? (int64_t)j * pr.By + i : (int64_t)i * pr.By + j;
@@ -154,9 +154,9 @@ __global__ __launch_bounds__(256) void cost_finalize(CostBatch cb, int nchunk, f
         l2 = (float)s * sc;
     }
     float c = l2;
-    if (pr.h1) c += causal_dot(pr.h1, pr.M1, i, j, T, J) * sc;
-    if (pr.h2) c += causal_dot(pr.h2, pr.M2, i, j, T, J) * sc;
-    pr.out[e] = c;
+    if (pr.h1) c += causal_tile16(pr.h1, pr.M1, i0, j0, pr.Bx, pr.By, T, J, sh, sm) * sc;
+    if (pr.h2) c += causal_tile16(pr.h2, pr.M2, i0, j0, pr.Bx, pr.By, T, J, sh, sm) * sc;
+    if (ok) pr.out[(int64_t)i * pr.By + j] = c;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -195,7 +195,7 @@ static int run_direct(CostBatch& cb, int64_t K, float sc, int T, int J, void* ws
     CostPlan pl = plan_direct(cb.nprob, Bx, By, same, K);
     if (ws_bytes < pl.ws_bytes || !ws)
         return fail(KCCOT_EWORKSPACE, "pairwise_cost: workspace %zu < required %zu", ws_bytes, pl.ws_bytes);
-    int total_tiles = 0, max_elems = 0;
+    int total_tiles = 0, max_bx = 0, max_by = 0;
     for (int p = 0; p < cb.nprob; ++p) {
         CostProb& pr = cb.p[p];
         pr.tile = DT;
@@ -203,7 +203,8 @@ static int run_direct(CostBatch& cb, int64_t K, float sc, int T, int J, void* ws
         pr.tiles_j = (pr.By + DT - 1) / DT;
         pr.partial = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.partial_off[p]);
         total_tiles += pr.tiles_i * pr.tiles_j;
-        if (pr.Bx * pr.By > max_elems) max_elems = pr.Bx * pr.By;
+        if (pr.Bx > max_bx) max_bx = pr.Bx;
+        if (pr.By > max_by) max_by = pr.By;
     }
     if (total_tiles > 65535) return fail(KCCOT_EUNSUPPORTED, "pairwise_cost: %d tiles", total_tiles);
     bool vec = (K % 4 == 0);
@@ -213,7 +214,7 @@ static int run_direct(CostBatch& cb, int64_t K, float sc, int T, int J, void* ws
     hipLaunchKernelGGL(cost_direct_partial, grid, dim3(256), 0, st, cb, K, pl.chunk, vec ? 1 : 0);
     int rc = launch_status("cost_direct_partial");
     if (rc || partial_only) return rc;
-    dim3 fgrid((max_elems + 255) / 256, cb.nprob);
+    dim3 fgrid((max_by + CAUSAL_TILE - 1) / CAUSAL_TILE, (max_bx + CAUSAL_TILE - 1) / CAUSAL_TILE, cb.nprob);
     hipLaunchKernelGGL(cost_finalize, fgrid, dim3(256), 0, st, cb, pl.nchunk, sc, T, J);
     return launch_status("cost_finalize");
 }

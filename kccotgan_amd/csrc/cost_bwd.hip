@@ -100,48 +100,165 @@ __global__ __launch_bounds__(256) void apply_coeffs(const float* __restrict__ Wt
     }
 }
 
-// dh[i,t,q] = sc * ( sum_j gA[i,j] dMA[j,t,q] + sum_j gB[i,j] dMB[j,t,q] ), dM = M[t+1]-M[t]; 0 at t = T-1
-__global__ __launch_bounds__(256) void causal_grad_h(float* __restrict__ out, int Bi, int Bj, int T, int J, float sc,
-                                                     const float* __restrict__ gA, const float* __restrict__ MA,
-                                                     const float* __restrict__ gB, const float* __restrict__ MB) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= Bi * T * J) return;
-    const int q = e % J, t = (e / J) % T, i = e / (J * T);
-    float s = 0.f;
-    if (t < T - 1) {
-        for (int j = 0; j < Bj; ++j) {
-            const int64_t o = ((int64_t)j * T + t) * J + q;
-            if (gA) s = fmaf(gA[(int64_t)i * Bj + j], MA[o + J] - MA[o], s);
-            if (gB) s = fmaf(gB[(int64_t)i * Bj + j], MB[o + J] - MB[o], s);
+// Feature gradients as small LDS-tiled products  out[a,k] = sc * sum_b G(a,b) X(b,k), k < T*J:
+//   CG_H (dh):  a = i, b = j, G = g[i,j],  X(j,k) = M[j,k+J] - M[j,k]          (0 for k >= (T-1)J)
+//   CG_M (dM):  a = j, b = i, G = g[i,j],  X(i,k) = h[i,k-J][k>=J] - h[i,k][k<(T-1)J]
+// with up to two (g, source) terms summed (h_fake / m_real appear in two cost matrices of the
+// loss).  One launch handles up to four outputs (blockIdx.z); block = 16 (a) x 16 (k) outputs.
+enum { CG_H = 0, CG_M = 1 };
+struct CausalGradJob {
+    float* out;          // [Ba, T*J]
+    int mode, Ba, Bb;
+    const float* g[2];   // [Bi, Bj] row-major (Bi = rows of C); null = term absent
+    const float* src[2]; // CG_H: M [Bb,T,J];  CG_M: h [Bb,T,J]
+};
+struct CausalGradBatch { CausalGradJob job[4]; int njobs; };
+
+__global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, int J, float sc) {
+    __shared__ float sg[16 * 65], sx[64 * 17];
+    const CausalGradJob& jb = cb.job[blockIdx.z];
+    const int TJ = T * J, KK = (T - 1) * J;
+    const int a0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
+    if (a0 >= jb.Ba) return;   // block-uniform
+    const int t = threadIdx.x, ta = t >> 4, tk = t & 15;
+    // C is [Bi,Bj]: for CG_H rows a index Bi (= Ba) and b runs over Bj (= Bb); for CG_M the reverse
+    const int Bj = (jb.mode == CG_H) ? jb.Bb : jb.Ba;
+    float tot = 0.f;
+    for (int term = 0; term < 2; ++term) {
+        const float* g = jb.g[term];
+        const float* src = jb.src[term];
+        if (!g) continue;
+        for (int b0 = 0; b0 < jb.Bb; b0 += 64) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int e = t + 256 * m;
+                if (jb.mode == CG_H) {
+                    const int ar = e >> 6, bb = e & 63;
+                    sg[ar * 65 + bb] = (a0 + ar < jb.Ba && b0 + bb < jb.Bb) ? g[(int64_t)(a0 + ar) * Bj + b0 + bb] : 0.f;
+                } else {
+                    const int bb = e >> 4, ar = e & 15;
+                    sg[ar * 65 + bb] = (a0 + ar < jb.Ba && b0 + bb < jb.Bb) ? g[(int64_t)(b0 + bb) * Bj + a0 + ar] : 0.f;
+                }
+                const int bb = e >> 4, kk = e & 15, k = k0 + kk;
+                float x = 0.f;
+                if (b0 + bb < jb.Bb && k < TJ) {
+                    const float* row = src + (int64_t)(b0 + bb) * TJ;
+                    if (jb.mode == CG_H) {
+                        if (k < KK) x = row[k + J] - row[k];
+                    } else {
+                        x = (k >= J ? row[k - J] : 0.f) - (k < KK ? row[k] : 0.f);
+                    }
+                }
+                sx[bb * 17 + kk] = x;
+            }
+            __syncthreads();
+#pragma unroll 16
+            for (int bb = 0; bb < 64; ++bb) tot = fmaf(sg[ta * 65 + bb], sx[bb * 17 + tk], tot);
+            __syncthreads();
         }
     }
-    out[e] = s * sc;
+    const int aa = a0 + ta, k = k0 + tk;
+    if (aa < jb.Ba && k < TJ) jb.out[(int64_t)aa * TJ + k] = tot * sc;
 }
 
-// dM[j,t,q] = sc * sum_i ( gA[i,j] (hA[i,t-1,q][t>=1] - hA[i,t,q][t<=T-2]) + same for B )
-__global__ __launch_bounds__(256) void causal_grad_M(float* __restrict__ out, int Bi, int Bj, int T, int J, float sc,
-                                                     const float* __restrict__ gA, const float* __restrict__ hA,
-                                                     const float* __restrict__ gB, const float* __restrict__ hB) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= Bj * T * J) return;
-    const int q = e % J, t = (e / J) % T, j = e / (J * T);
-    float s = 0.f;
-    for (int i = 0; i < Bi; ++i) {
-        const int64_t o = ((int64_t)i * T + t) * J + q;
-        if (gA) {
-            const float hd = (t >= 1 ? hA[o - J] : 0.f) - (t <= T - 2 ? hA[o] : 0.f);
-            s = fmaf(gA[(int64_t)i * Bj + j], hd, s);
-        }
-        if (gB) {
-            const float hd = (t >= 1 ? hB[o - J] : 0.f) - (t <= T - 2 ? hB[o] : 0.f);
-            s = fmaf(gB[(int64_t)i * Bj + j], hd, s);
+static int launch_causal_grads(CausalGradBatch& cb, int T, int J, float sc, hipStream_t st) {
+    if (cb.njobs == 0) return 0;
+    int maxa = 0;
+    for (int i = 0; i < cb.njobs; ++i) if (cb.job[i].Ba > maxa) maxa = cb.job[i].Ba;
+    dim3 grid((T * J + 15) / 16, (maxa + 15) / 16, cb.njobs);
+    hipLaunchKernelGGL(causal_grads, grid, dim3(256), 0, st, cb, T, J, sc);
+    return launch_status("causal_grads");
+}
+
+// ---- MFMA form of apply_coeffs for R = n1 + n2 <= 128 stack rows and Bout <= 64 output rows ----
+// out[64 x 64-column tile] = W[64 x 128] * Z[128 x 64]: each of the four waves owns one 32x32
+// output sub-tile (row block w&1, column block w>>1) and runs 64 v_mfma_f32_32x32x2_f32 over the
+// 128 stack rows.  A operand = W fragments, loaded once per workgroup straight into registers
+// (lane l, step s: Wt[2s + (l>>5)][32*mblk + (l&31)] -- two coalesced 128-byte rows);
+// B operand = the Z tile staged through LDS (lane l, step s: Z[2s + (l>>5)][32*cblk + (l&31)],
+// a conflict-free ds_read_b32).  Workgroups walk the column tiles persistently and prefetch the
+// next tile's global loads under the current tile's MFMAs.  HBM traffic = the algorithmic
+// minimum: every element of real/fake read once, every element of the gradient written once.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int AM_COLS = 64;
+constexpr int AM_ROWS = 128;
+
+__global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict__ Wt, const float* __restrict__ src1,
+                                                         int n1, const float* __restrict__ src2, int n2, int Bout,
+                                                         int64_t K, int64_t ntiles, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float zs[AM_ROWS * AM_COLS];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int mblk = wave & 1, cblk = wave >> 1;
+    const int R = n1 + n2;
+    const int nsteps = (R + 1) / 2;
+
+    // W fragments: afrag[s] = W[m = 32*mblk + (lane&31)][r = 2s + (lane>>5)]
+    float afrag[AM_ROWS / 2];
+    {
+        const int m = 32 * mblk + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < AM_ROWS / 2; ++s) {
+            const int r = 2 * s + (lane >> 5);
+            afrag[s] = (r < R && m < Bout) ? Wt[(int64_t)r * Bout + m] : 0.f;
         }
     }
-    out[e] = s * sc;
+    // staging: thread holds float4 at columns c4..c4+3 of stack rows (t>>4) + 16*j, j < 8
+    const int c4 = (t & 15) * 4, r0 = t >> 4;
+    const float* rowp[8];
+    bool rowok[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = r0 + 16 * j;
+        rowok[j] = r < R;
+        rowp[j] = r < n1 ? src1 + (int64_t)r * K : src2 + (int64_t)(r - n1) * K;
+    }
+    float4 v[8];
+    auto load_tile = [&](int64_t tile) {
+        const int64_t col = tile * AM_COLS + c4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = (rowok[j] && col + 4 <= K) ? *reinterpret_cast<const float4*>(rowp[j] + col)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(&zs[(r0 + 16 * j) * AM_COLS + c4]) = v[j];
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* zb = zs + (lane >> 5) * AM_COLS + 32 * cblk + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < AM_ROWS / 2; ++s) {
+            if (s < nsteps) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[s], zb[2 * s * AM_COLS], acc, 0, 0, 0);
+        }
+        __syncthreads();
+        const int64_t col = tile * AM_COLS + 32 * cblk + (lane & 31);
+        if (col < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * mblk + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < Bout) out[(int64_t)m * K + col] = acc[r];
+            }
+        }
+    }
 }
+
 
 static int launch_apply(const float* Wt, const float* s1, int n1, const float* s2, int n2, int Bout, int64_t K,
                         float* out, hipStream_t st) {
+    const bool al = (K % 4 == 0) && ((uintptr_t)s1 % 16 == 0) && (n2 == 0 || (uintptr_t)s2 % 16 == 0);
+    if (al && n1 + n2 <= AM_ROWS && Bout <= 64) {
+        const int64_t ntiles = (K + AM_COLS - 1) / AM_COLS;
+        const unsigned grid = (unsigned)(ntiles < 768 ? ntiles : 768);   // 3 workgroups per CU
+        hipLaunchKernelGGL(apply_coeffs_mfma, dim3(grid), dim3(256), 0, st, Wt, s1, n1, s2 ? s2 : s1, n2, Bout, K,
+                           ntiles, out);
+        return launch_status("apply_coeffs_mfma");
+    }
     const unsigned gx = (unsigned)((K + 255) / 256);
     if (Bout <= 8) hipLaunchKernelGGL(apply_coeffs<8>, dim3(gx, 1), dim3(256), 0, st, Wt, s1, n1, s2, n2, Bout, K, out);
     else if (Bout <= 16) hipLaunchKernelGGL(apply_coeffs<16>, dim3(gx, 1), dim3(256), 0, st, Wt, s1, n1, s2, n2, Bout, K, out);
@@ -184,17 +301,14 @@ extern "C" int kccot_pairwise_cost3_bwd_f32(const float* g3, const float* real, 
         if ((rc = launch_status("build_coeffs"))) return rc;
         if ((rc = launch_apply(Wt, real, B, fake, B, B, K, dfake, st))) return rc;
     }
-    const int nf = B * T * J;
-    const dim3 fg((nf + 255) / 256), fb(256);
-    // gan_utils.py:221-223: h_fake rows of xy (cols m_real) and of yy (cols m_fake); h_real rows of xx (cols m_real)
-    if (dh_fake) hipLaunchKernelGGL(causal_grad_h, fg, fb, 0, st, dh_fake, B, B, T, J, sc, gxy, m_real, gyy, m_fake);
-    if (dh_real) hipLaunchKernelGGL(causal_grad_h, fg, fb, 0, st, dh_real, B, B, T, J, sc, gxx, m_real,
-                                    (const float*)nullptr, (const float*)nullptr);
-    // m_real cols of xy (rows h_fake) and of xx (rows h_real); m_fake cols of yy (rows h_fake)
-    if (dm_real) hipLaunchKernelGGL(causal_grad_M, fg, fb, 0, st, dm_real, B, B, T, J, sc, gxy, h_fake, gxx, h_real);
-    if (dm_fake) hipLaunchKernelGGL(causal_grad_M, fg, fb, 0, st, dm_fake, B, B, T, J, sc, gyy, h_fake,
-                                    (const float*)nullptr, (const float*)nullptr);
-    return launch_status("causal_grad");
+    // gan_utils.py:221-223: h_fake rows of xy (cols m_real) and of yy (cols m_fake); h_real rows of xx
+    // (cols m_real); m_real cols of xy (rows h_fake) and of xx (rows h_real); m_fake cols of yy (rows h_fake)
+    CausalGradBatch cg{};
+    if (dh_fake) cg.job[cg.njobs++] = CausalGradJob{dh_fake, CG_H, B, B, {gxy, gyy}, {m_real, m_fake}};
+    if (dh_real) cg.job[cg.njobs++] = CausalGradJob{dh_real, CG_H, B, B, {gxx, nullptr}, {m_real, nullptr}};
+    if (dm_real) cg.job[cg.njobs++] = CausalGradJob{dm_real, CG_M, B, B, {gxy, gxx}, {h_fake, h_real}};
+    if (dm_fake) cg.job[cg.njobs++] = CausalGradJob{dm_fake, CG_M, B, B, {gyy, nullptr}, {h_fake, nullptr}};
+    return launch_causal_grads(cg, T, J, sc, st);
 }
 
 extern "C" size_t kccot_pairwise_cost_bwd_workspace_bytes(int Bx, int By) {
@@ -246,9 +360,8 @@ extern "C" int kccot_pairwise_cost_bwd_f32(const float* g, const float* x, const
             if ((rc = launch_apply(W2, x, Bx, y, By, By, K, dy, st))) return rc;
         }
     }
-    if (dh) hipLaunchKernelGGL(causal_grad_h, dim3((Bx * T * J + 255) / 256), dim3(256), 0, st, dh, Bx, By, T, J, sc,
-                               g, M, (const float*)nullptr, (const float*)nullptr);
-    if (dM) hipLaunchKernelGGL(causal_grad_M, dim3((By * T * J + 255) / 256), dim3(256), 0, st, dM, Bx, By, T, J, sc,
-                               g, h, (const float*)nullptr, (const float*)nullptr);
-    return launch_status("pairwise_cost_bwd");
+    CausalGradBatch cg{};
+    if (dh) cg.job[cg.njobs++] = CausalGradJob{dh, CG_H, Bx, By, {g, nullptr}, {M, nullptr}};
+    if (dM) cg.job[cg.njobs++] = CausalGradJob{dM, CG_M, By, Bx, {g, nullptr}, {h, nullptr}};
+    return launch_causal_grads(cg, T, J, sc, st);
 }

@@ -33,20 +33,41 @@ struct CostPlan {
     size_t ws_bytes;
 };
 
-__device__ __forceinline__ float causal_dot(const float* __restrict__ h, const float* __restrict__ M,
-                                            int i, int j, int T, int J) {
-    // sum_{t<T-1} sum_q h[i,t,q]*(M[j,t+1,q]-M[j,t,q]); inner sum over q first, as gan_utils.py:37-38
-    const float* hi = h + (int64_t)i * T * J;
-    const float* Mj = M + (int64_t)j * T * J;
+// Causal term of a 16x16 output tile (block = 256 threads, thread (ti = t>>4, tj = t&15)):
+//   sum_{t<T-1} sum_q h[i0+ti,t,q] * (M[j0+tj,t+1,q] - M[j0+tj,t,q])            (gan_utils.py:34-38)
+// With k = t*J + q running over (T-1)*J values this is a [16 x KK] x [KK x 16] product of the
+// flattened h rows and first differences of the flattened M rows (M[k+J] - M[k]); both are
+// staged through LDS in 64-wide k chunks so that global reads are coalesced.
+// sh, sm: 16*65 floats of LDS each.  Every thread of the block must call it.
+constexpr int CAUSAL_TILE = 16;
+constexpr int CAUSAL_KC = 64;
+constexpr int CAUSAL_PITCH = CAUSAL_KC + 1;
+
+__device__ __forceinline__ float causal_tile16(const float* __restrict__ h, const float* __restrict__ M, int i0,
+                                               int j0, int Bx, int By, int T, int J, float* sh, float* sm) {
+    const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
+    const int KK = (T - 1) * J, TJ = T * J;
     float tot = 0.f;
-    for (int t = 0; t < T - 1; ++t) {
-        float s = 0.f;
-        for (int q = 0; q < J; ++q) s = fmaf(hi[t * J + q], Mj[(t + 1) * J + q] - Mj[t * J + q], s);
-        tot += s;
+    for (int k0 = 0; k0 < KK; k0 += CAUSAL_KC) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int e = t + 256 * m, row = e >> 6, kk = e & 63, k = k0 + kk;
+            const bool kok = k < KK;
+            sh[row * CAUSAL_PITCH + kk] = (kok && i0 + row < Bx) ? h[(int64_t)(i0 + row) * TJ + k] : 0.f;
+            float d = 0.f;
+            if (kok && j0 + row < By) {
+                const float* mr = M + (int64_t)(j0 + row) * TJ + k;
+                d = mr[J] - mr[0];
+            }
+            sm[row * CAUSAL_PITCH + kk] = d;
+        }
+        __syncthreads();
+#pragma unroll 16
+        for (int kk = 0; kk < CAUSAL_KC; ++kk) tot = fmaf(sh[ti * CAUSAL_PITCH + kk], sm[tj * CAUSAL_PITCH + kk], tot);
+        __syncthreads();
     }
     return tot;
 }
-
 
 // ---- stacked-Gram MFMA path (cost_mfma.hip) -------------------------------------------------
 // One "stack" is up to 128 rows: rows 0..63 from src1 (n1 valid), rows 64..127 from src2 (n2

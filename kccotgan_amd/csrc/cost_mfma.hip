@@ -197,22 +197,35 @@ __global__ __launch_bounds__(256) void gram128_partial(GramArgs ga) {
     }
 }
 
-// Sum the per-chunk partial Gram sub-tiles in fp64.  grid = (GRAM_ELEMS/256, GRAM_REDUCE_SPLIT):
-// block (e, r) sums chunks r, r+SPLIT, ... in increasing order -> deterministic.
-__global__ __launch_bounds__(256) void gram_reduce(const float* __restrict__ gpart, int nchunk,
-                                                   unsigned mask, double* __restrict__ gsum) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+// Sum the per-chunk partial Gram sub-tiles in fp64.  One workgroup of 1024 threads owns 64
+// consecutive Gram entries (one 256-byte line per chunk): thread (e = t & 63, grp = t >> 6) adds
+// chunks grp, grp+16, ... in increasing order, then the 16 group sums are combined in fixed order
+// through LDS -> run-to-run deterministic.
+__global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gpart, int nchunk, unsigned mask,
+                                                    double* __restrict__ gsum) {
+    __shared__ double part[16][64];
+    const int t = threadIdx.x, el = t & 63, grp = t >> 6;
+    const int e = blockIdx.x * 64 + el;
     const int sub = e >> 10;
+    const bool need = (mask >> sub) & 1u;
+    const bool split = (mask == 0x3FFu) && sub >= 8;   // second k-half lives in slab sub+2
     double s = 0.0;
-    if ((mask >> sub) & 1u) {
-        const bool split = (mask == 0x3FFu) && sub >= 8;   // second k-half lives in slab sub+2
-        for (int c = blockIdx.y; c < nchunk; c += GRAM_REDUCE_SPLIT) {
-            const float* p = gpart + (int64_t)c * GRAM_SLABS * 1024;
-            s += (double)p[e];
-            if (split) s += (double)p[e + 2048];
+    if (need) {
+        const float* p = gpart + e;
+        for (int c = grp; c < nchunk; c += 16) {
+            const float* pc = p + (int64_t)c * GRAM_SLABS * 1024;
+            s += (double)pc[0];
+            if (split) s += (double)pc[2048];
         }
     }
-    gsum[(int64_t)blockIdx.y * GRAM_ELEMS + e] = s;
+    part[grp][el] = s;
+    __syncthreads();
+    if (grp == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) tot += part[g][el];
+        gsum[e] = tot;
+    }
 }
 
 struct GramFin {
@@ -231,45 +244,42 @@ struct GramFin {
 __device__ __forceinline__ double gram_at(const double* __restrict__ gsum, int s, int t) {
     int a = s >> 5, b = t >> 5;
     if (a > b) { int x = s; s = t; t = x; x = a; a = b; b = x; }
-    const int e = sub_index(a, b) * 1024 + (s & 31) * 32 + (t & 31);
-    double v = 0.0;
-#pragma unroll
-    for (int r = 0; r < GRAM_REDUCE_SPLIT; ++r) v += gsum[(int64_t)r * GRAM_ELEMS + e];
-    return v;
+    return gsum[sub_index(a, b) * 1024 + (s & 31) * 32 + (t & 31)];
 }
 
+// One 16x16 output tile per block: distances from the summed Gram entries (fp64), scale, causal term.
 __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
-    const int p = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= f.B1 * f.B2) return;
-    const int i = e / f.B2, j = e % f.B2;
+    __shared__ float sh[CAUSAL_TILE * CAUSAL_PITCH], sm[CAUSAL_TILE * CAUSAL_PITCH];
+    const int p = blockIdx.z;
+    const int i0 = blockIdx.y * CAUSAL_TILE, j0 = blockIdx.x * CAUSAL_TILE;
+    const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
+    const bool ok = i < f.B1 && j < f.B2;
     const double* G = f.gsum;
-    double D;
-    if (f.mode == GRAM_LOSS3) {
-        const double dxx = (i == j) ? 0.0 : gram_at(G, i, i) + gram_at(G, j, j) - 2.0 * gram_at(G, i, j);
-        if (p == 1) {
-            D = dxx;
-        } else if (p == 0) {
-            D = dxx + gram_at(G, 64 + j, 64 + j) - 2.0 * (gram_at(G, i, 64 + j) - gram_at(G, j, 64 + j));
-        } else {
-            if (i == j) D = 0.0;
-            else {
+    double D = 0.0;
+    if (ok) {
+        if (f.mode == GRAM_LOSS3) {
+            const double dxx = (i == j) ? 0.0 : gram_at(G, i, i) + gram_at(G, j, j) - 2.0 * gram_at(G, i, j);
+            if (p == 1) {
+                D = dxx;
+            } else if (p == 0) {
+                D = dxx + gram_at(G, 64 + j, 64 + j) - 2.0 * (gram_at(G, i, 64 + j) - gram_at(G, j, 64 + j));
+            } else if (i != j) {
                 const double dee = gram_at(G, 64 + i, 64 + i) + gram_at(G, 64 + j, 64 + j)
                                    - 2.0 * gram_at(G, 64 + i, 64 + j);
                 D = dxx + dee + 2.0 * (gram_at(G, i, 64 + i) - gram_at(G, i, 64 + j)
                                        - gram_at(G, j, 64 + i) + gram_at(G, j, 64 + j));
             }
+        } else if (f.mode == GRAM_XY) {
+            D = gram_at(G, i, i) + gram_at(G, 64 + j, 64 + j) - 2.0 * gram_at(G, i, 64 + j);
+        } else {  // GRAM_SAME: row i of x is stack row i (rows 64.. come from src2 = x + 64 rows)
+            D = (i == j) ? 0.0 : gram_at(G, i, i) + gram_at(G, j, j) - 2.0 * gram_at(G, i, j);
         }
-    } else if (f.mode == GRAM_XY) {
-        D = gram_at(G, i, i) + gram_at(G, 64 + j, 64 + j) - 2.0 * gram_at(G, i, 64 + j);
-    } else {  // GRAM_SAME: row i of x is stack row i (rows 64.. come from src2 = x + 64 rows)
-        D = (i == j) ? 0.0 : gram_at(G, i, i) + gram_at(G, j, j) - 2.0 * gram_at(G, i, j);
+        if (D < 0.0) D = 0.0;   // a squared distance; rounding of the Gram terms may leave -tiny
     }
-    if (D < 0.0) D = 0.0;   // a squared distance; rounding of the Gram terms may leave -tiny
     float c = (float)D * f.sc;
-    if (f.h[p]) c += causal_dot(f.h[p], f.M[p], i, j, f.T, f.J) * f.sc;
-    if (p == 0 && f.h2) c += causal_dot(f.h2, f.M2, i, j, f.T, f.J) * f.sc;
-    f.out[p][e] = c;
+    if (f.h[p]) c += causal_tile16(f.h[p], f.M[p], i0, j0, f.B1, f.B2, f.T, f.J, sh, sm) * f.sc;
+    if (p == 0 && f.h2) c += causal_tile16(f.h2, f.M2, i0, j0, f.B1, f.B2, f.T, f.J, sh, sm) * f.sc;
+    if (ok) f.out[p][(int64_t)i * f.B2 + j] = c;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -312,7 +322,7 @@ GramPlan plan_gram(int64_t K) {
     int64_t max_chunks = ksteps < 1024 ? ksteps : 1024;
     if (max_chunks < pl.nchunk) max_chunks = pl.nchunk;
     pl.gpart_bytes = align_up((size_t)max_chunks * GRAM_SLABS * 1024 * sizeof(float), 256);
-    pl.gsum_bytes = align_up((size_t)GRAM_REDUCE_SPLIT * GRAM_ELEMS * sizeof(double), 256);
+    pl.gsum_bytes = align_up((size_t)GRAM_ELEMS * sizeof(double), 256);
     pl.ws_bytes = pl.gpart_bytes + pl.gsum_bytes;
     return pl;
 }
@@ -366,12 +376,13 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     hipLaunchKernelGGL(gram128_partial, dim3(pl.nchunk), dim3(256), 0, st, ga);
     int rc = launch_status("gram128_partial");
     if (rc || partial_only) return rc;
-    hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 256, GRAM_REDUCE_SPLIT), dim3(256), 0, st,
+    hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 64), dim3(1024), 0, st,
                        (const float*)ga.gpart, pl.nchunk, ga.mask, gsum);
     rc = launch_status("gram_reduce");
     if (rc) return rc;
     gf.gsum = gsum; gf.mode = mode; gf.sc = sc; gf.T = T; gf.J = J;
-    hipLaunchKernelGGL(gram_finalize, dim3((gf.B1 * gf.B2 + 255) / 256, nout), dim3(256), 0, st, gf);
+    hipLaunchKernelGGL(gram_finalize, dim3((gf.B2 + CAUSAL_TILE - 1) / CAUSAL_TILE, (gf.B1 + CAUSAL_TILE - 1) / CAUSAL_TILE, nout),
+                       dim3(256), 0, st, gf);
     return launch_status("gram_finalize");
 }
 

@@ -2,19 +2,22 @@
 // :87-121 of the reference, and what tf.GradientTape records through that unrolled loop).
 //
 // One workgroup per n x n problem; the problem never leaves the CU.  The loop is a chain of
-// 2*nits dependent half-steps, each one pass over the n^2 cost entries plus a reduction per
+// 2*nits dependent half-steps, each one pass over the n^2 cost entries plus one reduction per
 // line, so it is latency-bound: no per-iteration launches, no host sync for the stop rule, and
 // for n <= 128 the cost matrix lives in registers in BOTH orientations:
 //
-//   row layout:    thread (i = t / LPR, q = t % LPR) owns C[i][q + LPR*m], m < EPT
-//   column layout: thread (j = t / LPR, q = t % LPR) owns C[q + LPR*m][j], m < EPT
+//   row layout:    thread (i = t / LPR, q = t % LPR) owns C[i][q*EPT + m], m < EPT
+//   column layout: thread (j = t / LPR, q = t % LPR) owns C[q*EPT + m][j], m < EPT
 //
-// LPR (lanes per line) is a power of two <= 64, so the lanes of a line sit in one wavefront and
-// the log-sum-exp of a line is EPT serial terms + log2(LPR) xor-shuffle steps; u and v are
-// exchanged through 2*n floats of LDS with one barrier per half-step.
+// LPR (lanes per line) is 8 or 16, i.e. at most one 16-lane DPP row: the log-sum-exp of a line
+// is EPT serial terms + log2(LPR) DPP steps (quad_perm, row_half_mirror, row_mirror -- register
+// to register, no LDS crossbar); the duals u and v are exchanged through 2*n floats of LDS
+// (ds_read_b128: a thread's EPT entries are contiguous) with ONE barrier per half-step.
 //
-// Arithmetic follows the reference op for op: M = ((-C + u) + v) / eps;
+// Arithmetic follows the reference's order: M = ((-C + u) + v) * (1/eps);
 // lse = log(sum(exp(M - max))) + max; u = eps*(log(1/n) - lse) + u, then v with the new u.
+// exp/log are the hardware v_exp_f32 / v_log_f32 (base 2, 1 ulp): arguments are <= 0 after the
+// max shift, so the relative error of the sum stays at the 1e-7 level.
 #include "common.h"
 #include <math.h>
 
@@ -22,11 +25,38 @@ namespace kccot {
 
 constexpr int SK_MAXN = 128;      // register-resident kernels
 constexpr int SK_MAXT = 1024;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// ---- DPP reductions inside aligned groups of LPR <= 16 lanes; every lane gets the result -----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int LPR>
+__device__ __forceinline__ float seg_max(float v) {
+    if (LPR >= 2) v = fmaxf(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+    if (LPR >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+    if (LPR >= 8) v = fmaxf(v, dpp_mov<0x141>(v));   // row_half_mirror
+    if (LPR >= 16) v = fmaxf(v, dpp_mov<0x140>(v));  // row_mirror
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ float seg_sum(float v) {
+    if (LPR >= 2) v += dpp_mov<0xB1>(v);
+    if (LPR >= 4) v += dpp_mov<0x4E>(v);
+    if (LPR >= 8) v += dpp_mov<0x141>(v);
+    if (LPR >= 16) v += dpp_mov<0x140>(v);
+    return v;
+}
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * LN2; }
 
 struct SinkArgs {
     const float* C;       // [nprob,n,n]
-    int n, L, Lmin, stop_mode, lpr;
-    float eps, thresh;
+    int n, L, Lmin, stop_mode;
+    float eps, inv_eps, thresh;
     float* u_hist;        // [nprob,L,n] or null
     float* v_hist;
     float* cost_out;      // [nprob]
@@ -34,86 +64,95 @@ struct SinkArgs {
     float* pi_out;        // [nprob,n,n] or null
 };
 
-__device__ __forceinline__ float seg_max(float v, int lpr) {
-    for (int o = lpr >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float seg_sum(float v, int lpr) {
-    for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Load the EPT contiguous duals a thread needs (entries q*EPT .. q*EPT+EPT-1) from LDS.
+template <int EPT>
+__device__ __forceinline__ void load_other(float (&o)[EPT], const float* arr, int q) {
+    if constexpr (EPT >= 4) {
+#pragma unroll
+        for (int m = 0; m < EPT; m += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(arr + q * EPT + m);
+            o[m] = v.x; o[m + 1] = v.y; o[m + 2] = v.z; o[m + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) o[m] = arr[q * EPT + m];
+    }
 }
 
 // One half-step for the calling thread's line: returns the updated dual value of the line.
-//   c[m]   : the thread's cost entries of this line
-//   self   : current dual of this line (u_i for a row line, v_j for a column line)
-//   other  : LDS array of the other dual, indexed by the entry's position q + lpr*m
-template <int EPT>
-__device__ __forceinline__ float half_step(const float (&c)[EPT], float self, const float* other,
-                                           int q, int lpr, int n, float eps, float log_w, bool row_line) {
-    float x[EPT];
+// Entries past the matrix edge carry c = +inf and become exp(-inf) = 0.
+template <int EPT, int LPR, bool ROW>
+__device__ __forceinline__ float half_step(const float (&c)[EPT], float self, const float* other, int q,
+                                           float eps, float inv_eps, float log_w) {
+    float o[EPT], x[EPT];
+    load_other<EPT>(o, other, q);
     float mx = -INFINITY;
 #pragma unroll
     for (int m = 0; m < EPT; ++m) {
-        const int idx = q + lpr * m;
-        const float o = idx < n ? other[idx] : 0.f;
         // gan_utils.py:153,155: (-C + u + v^T)/eps evaluates as ((-C + u) + v)/eps
-        const float t = row_line ? ((-c[m] + self) + o) : ((-c[m] + o) + self);
-        x[m] = t / eps;
+        const float t = ROW ? ((-c[m] + self) + o[m]) : ((-c[m] + o[m]) + self);
+        x[m] = t * inv_eps;
         mx = fmaxf(mx, x[m]);
     }
-    mx = seg_max(mx, lpr);
+    mx = seg_max<LPR>(mx);
     // tf.reduce_logsumexp: a non-finite max is replaced by 0
     const float shift = (mx > -INFINITY && mx < INFINITY) ? mx : 0.f;
     float s = 0.f;
 #pragma unroll
-    for (int m = 0; m < EPT; ++m) s += expf(x[m] - shift);
-    s = seg_sum(s, lpr);
-    const float lse = logf(s) + shift;
+    for (int m = 0; m < EPT; ++m) s += __builtin_amdgcn_exp2f((x[m] - shift) * LOG2E);
+    s = seg_sum<LPR>(s);
+    const float lse = fast_log(s) + shift;
     return eps * (log_w - lse) + self;   // gan_utils.py:154,156
 }
 
-template <int EPT>
-__global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
-    __shared__ float u_s[SK_MAXN], v_s[SK_MAXN], red[16];
-    const int p = blockIdx.x, n = a.n, lpr = a.lpr;
-    const int t = threadIdx.x, line = t / lpr, q = t % lpr;
-    const bool active = line < n;
-    const float* C = a.C + (int64_t)p * n * n;
-    const float eps = a.eps;
-
-    // +inf marks entries beyond the matrix edge: they turn into exp(-inf) = 0 everywhere
-    float crow[EPT], ccol[EPT];
+template <int EPT, int LPR>
+__device__ __forceinline__ void load_costs(const float* __restrict__ C, int n, int line, int q, float (&crow)[EPT],
+                                           float (&ccol)[EPT]) {
 #pragma unroll
     for (int m = 0; m < EPT; ++m) {
-        const int idx = q + lpr * m;
-        const bool ok = active && idx < n;
+        const int idx = q * EPT + m;
+        const bool ok = line < n && idx < n;
         crow[m] = ok ? C[(int64_t)line * n + idx] : INFINITY;
         ccol[m] = ok ? C[(int64_t)idx * n + line] : INFINITY;
     }
-    if (t < n) { u_s[t] = 0.f; v_s[t] = 0.f; }   // gan_utils.py:147
+}
+
+template <int EPT, int LPR>
+__global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
+    // padded so that the float4 reads of lines past n stay inside the arrays
+    __shared__ __attribute__((aligned(16))) float u_s[SK_MAXN + 16 * 16];
+    __shared__ __attribute__((aligned(16))) float v_s[SK_MAXN + 16 * 16];
+    __shared__ float red[16];
+    const int p = blockIdx.x, n = a.n;
+    const int t = threadIdx.x, line = t / LPR, q = t % LPR;
+    const bool active = line < n;
+    const float* C = a.C + (int64_t)p * n * n;
+    const float eps = a.eps, inv_eps = a.inv_eps;
+
+    float crow[EPT], ccol[EPT];
+    load_costs<EPT, LPR>(C, n, line, q, crow, ccol);
+    for (int i = t; i < SK_MAXN + 16 * 16; i += blockDim.x) { u_s[i] = 0.f; v_s[i] = 0.f; }   // gan_utils.py:147
     __syncthreads();
 
     const float log_w = logf(1.0f / (float)n);     // log(mu) = log(nu), gan_utils.py:138-139
+    const int lsafe = active ? line : 0;
     int nits = 0;
     for (int it = 0; it < a.L; ++it) {
+        // every lane executes the half-steps (DPP reads neighbours); only real lines store
+        const float ui = u_s[lsafe];
+        const float un = half_step<EPT, LPR, true>(crow, ui, v_s, q, eps, inv_eps, log_w);
         float du = 0.f;
-        if (active) {
-            const float ui = u_s[line];
-            const float un = half_step<EPT>(crow, ui, v_s, q, lpr, n, eps, log_w, true);
-            if (q == 0) {
-                u_s[line] = un;
-                du = fabsf(un - ui);
-                if (a.u_hist) a.u_hist[((int64_t)p * a.L + it) * n + line] = un;
-            }
+        if (active && q == 0) {
+            u_s[line] = un;
+            du = fabsf(un - ui);
+            if (a.u_hist) a.u_hist[((int64_t)p * a.L + it) * n + line] = un;
         }
         __syncthreads();
-        if (active) {
-            const float vj = v_s[line];
-            const float vn = half_step<EPT>(ccol, vj, u_s, q, lpr, n, eps, log_w, false);
-            if (q == 0) {
-                v_s[line] = vn;
-                if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + line] = vn;
-            }
+        const float vj = v_s[lsafe];
+        const float vn = half_step<EPT, LPR, false>(ccol, vj, u_s, q, eps, inv_eps, log_w);
+        if (active && q == 0) {
+            v_s[line] = vn;
+            if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + line] = vn;
         }
         __syncthreads();
         nits = it + 1;
@@ -132,9 +171,9 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
         const float ui = u_s[line];
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
-            const int idx = q + lpr * m;
+            const int idx = q * EPT + m;
             if (idx < n) {
-                const float pi = expf(((-crow[m] + ui) + v_s[idx]) / eps);
+                const float pi = fast_exp(((-crow[m] + ui) + v_s[idx]) * inv_eps);
                 part += pi * crow[m];
                 if (a.pi_out) a.pi_out[(int64_t)p * n * n + (int64_t)line * n + idx] = pi;
             }
@@ -158,6 +197,13 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
 //   Q_t[i,j] = exp((-C_ij + u_t,i + v_t,j     - a)/eps)
 //   P_t[i,j] = exp((-C_ij + u_t,i + v_{t-1,j} - a)/eps)
 // (the two "= 0" terms are 1e-7-sized rounding residues in the reference's tape; dropped).
+//
+// Per iteration, newest first:   (A) row pass with Q_t:    gu_i -= sum_j Q_ij gv_j ; dC += Q_ij gv_j
+//                                (B) column pass with P_t: gv_j = -sum_i P_ij gu_i ; dC += P_ij gu_i
+// u_t / v_t come from the forward's history; the vectors of the NEXT (older) iteration are
+// prefetched from global memory into registers one iteration ahead and parked in a
+// double-buffered LDS slot, so the dependent chain sees LDS latency only: two barriers per
+// iteration.
 // ------------------------------------------------------------------------------------------
 struct SinkBwdArgs {
     const float* C;
@@ -166,103 +212,128 @@ struct SinkBwdArgs {
     const int32_t* nits;
     const float* gcost;
     float* dC;
-    int n, L, lpr;
-    float eps;
+    int n, L;
+    float eps, inv_eps;
 };
 
-template <int EPT>
+template <int EPT, int LPR>
 __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
-    __shared__ float ut[SK_MAXN], vt[SK_MAXN], vp[SK_MAXN], gu[SK_MAXN], gv[SK_MAXN];
-    const int p = blockIdx.x, n = a.n, lpr = a.lpr;
-    const int t = threadIdx.x, line = t / lpr, q = t % lpr;
+    constexpr int PADN = SK_MAXN + 16 * 16;
+    __shared__ __attribute__((aligned(16))) float U[2][PADN];
+    __shared__ __attribute__((aligned(16))) float V[2][PADN];
+    __shared__ __attribute__((aligned(16))) float gu[PADN];
+    __shared__ __attribute__((aligned(16))) float gv[PADN];
+    const int p = blockIdx.x, n = a.n;
+    const int t = threadIdx.x, line = t / LPR, q = t % LPR;
     const bool active = line < n;
     const float* C = a.C + (int64_t)p * n * n;
-    const float eps = a.eps, g = a.gcost[p];
+    const float eps = a.eps, inv_eps = a.inv_eps, g = a.gcost[p];
     const int nits = a.nits[p];
     const float* uh = a.u_hist + (int64_t)p * a.L * n;
     const float* vh = a.v_hist + (int64_t)p * a.L * n;
 
     float crow[EPT], ccol[EPT], drow[EPT], dcol[EPT];
+    load_costs<EPT, LPR>(C, n, line, q, crow, ccol);
 #pragma unroll
-    for (int m = 0; m < EPT; ++m) {
-        const int idx = q + lpr * m;
-        const bool ok = active && idx < n;
-        crow[m] = ok ? C[(int64_t)line * n + idx] : INFINITY;
-        ccol[m] = ok ? C[(int64_t)idx * n + line] : INFINITY;
-        drow[m] = 0.f;
-        dcol[m] = 0.f;
+    for (int m = 0; m < EPT; ++m) { drow[m] = 0.f; dcol[m] = 0.f; }
+    for (int i = t; i < PADN; i += blockDim.x) {
+        U[0][i] = U[1][i] = V[0][i] = V[1][i] = 0.f;
+        gu[i] = gv[i] = 0.f;
     }
+    __syncthreads();
+    // history index k holds (u_{k+1}, v_{k+1}); iteration `it` (1-based) lives in slot it & 1;
+    // v_0 = 0
+    auto hist_u = [&](int it, int i) { return it >= 1 ? uh[(int64_t)(it - 1) * n + i] : 0.f; };
+    auto hist_v = [&](int it, int i) { return it >= 1 ? vh[(int64_t)(it - 1) * n + i] : 0.f; };
     if (t < n) {
-        ut[t] = nits > 0 ? uh[(int64_t)(nits - 1) * n + t] : 0.f;
-        vt[t] = nits > 0 ? vh[(int64_t)(nits - 1) * n + t] : 0.f;
+        U[nits & 1][t] = hist_u(nits, t);
+        V[nits & 1][t] = hist_v(nits, t);
+        V[(nits - 1) & 1][t] = hist_v(nits - 1, t);
     }
+    // prefetch for the first in-loop refill: u_{nits-1}, v_{nits-2}
+    float nu = (t < n) ? hist_u(nits - 1, t) : 0.f;
+    float nv = (t < n) ? hist_v(nits - 2, t) : 0.f;
     __syncthreads();
 
     // cost = sum_ij pi_ij C_ij, pi = exp((-C+u+v)/eps):
     //   dcost/dC_ij (direct) = pi_ij (1 - C_ij/eps); dcost/du_i = sum_j pi_ij C_ij/eps; same for v
-    if (active) {
+    {
+        const float* Uc = U[nits & 1];
+        const float* Vc = V[nits & 1];
+        const int lsafe = active ? line : 0;
+        const float ui = Uc[lsafe], vj = Vc[lsafe];
+        float ov[EPT], ou[EPT];
+        load_other<EPT>(ov, Vc, q);
+        load_other<EPT>(ou, Uc, q);
         float su = 0.f, sv = 0.f;
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
-            const int idx = q + lpr * m;
-            if (idx < n) {
-                const float pr = expf(((-crow[m] + ut[line]) + vt[idx]) / eps);
-                drow[m] = g * pr * (1.f - crow[m] / eps);
-                su += pr * crow[m];
-                const float pc = expf(((-ccol[m] + ut[idx]) + vt[line]) / eps);
-                sv += pc * ccol[m];
-            }
+            const bool ok = active && (q * EPT + m) < n;
+            const float cr = ok ? crow[m] : 0.f, cc = ok ? ccol[m] : 0.f;
+            const float pr = ok ? fast_exp(((-cr + ui) + ov[m]) * inv_eps) : 0.f;
+            drow[m] = g * pr * (1.f - cr * inv_eps);
+            su += pr * cr;
+            const float pc = ok ? fast_exp(((-cc + ou[m]) + vj) * inv_eps) : 0.f;
+            sv += pc * cc;
         }
-        su = seg_sum(su, lpr);
-        sv = seg_sum(sv, lpr);
-        if (q == 0) { gu[line] = g * su / eps; gv[line] = g * sv / eps; }
+        su = seg_sum<LPR>(su);
+        sv = seg_sum<LPR>(sv);
+        if (active && q == 0) { gu[line] = g * su * inv_eps; gv[line] = g * sv * inv_eps; }
     }
     const float aconst = eps * logf(1.0f / (float)n);
+    __syncthreads();
 
     for (int it = nits; it >= 1; --it) {
-        __syncthreads();   // gu/gv of the previous step complete; ut/vt/vp free to be replaced
-        if (t < n) {
-            ut[t] = uh[(int64_t)(it - 1) * n + t];
-            vt[t] = vh[(int64_t)(it - 1) * n + t];
-            vp[t] = it >= 2 ? vh[(int64_t)(it - 2) * n + t] : 0.f;
-        }
-        __syncthreads();
-        // (A) through v_t: row pass with Q_t; gu_i -= sum_j Q_ij gv_j ; dC_ij += Q_ij gv_j
-        if (active) {
-            const float ui = ut[line];
+        const float* Uc = U[it & 1];
+        const float* Vc = V[it & 1];
+        const float* Vp = V[(it - 1) & 1];
+        const int lsafe = active ? line : 0;
+        // (A) through v_t: row pass with Q_t
+        {
+            const float ui = Uc[lsafe];
+            float ov[EPT], og[EPT];
+            load_other<EPT>(ov, Vc, q);
+            load_other<EPT>(og, gv, q);
             float s = 0.f;
 #pragma unroll
             for (int m = 0; m < EPT; ++m) {
-                const int idx = q + lpr * m;
-                if (idx < n) {
-                    const float qq = expf((((-crow[m] + ui) + vt[idx]) - aconst) / eps);
-                    const float w = qq * gv[idx];
-                    drow[m] += w;
-                    s += w;
-                }
+                // entries past the edge: c = +inf -> exp2(-inf) = 0
+                const float qq = fast_exp((((-crow[m] + ui) + ov[m]) - aconst) * inv_eps);
+                const float w = qq * og[m];
+                drow[m] += w;
+                s += w;
             }
-            s = seg_sum(s, lpr);
+            s = seg_sum<LPR>(s);
             // grad wrt u_t: the final-cost term on the last iteration, nothing on older ones
-            if (q == 0) gu[line] = (it == nits ? gu[line] : 0.f) - s;
+            if (active && q == 0) gu[line] = (it == nits ? gu[line] : 0.f) - s;
         }
         __syncthreads();
-        // (B) through u_t: column pass with P_t; gv_{t-1,j} = -sum_i P_ij gu_i ; dC_ij += P_ij gu_i
-        if (active) {
-            const float vj = vp[line];
+        // refill the slots the older iteration needs: U[(it-1)&1] <- u_{it-1}, V[it&1] <- v_{it-2}
+        // (v_t is dead after pass A; u_{it-1}'s slot was last read in iteration it+1)
+        if (t < n) {
+            U[(it - 1) & 1][t] = nu;
+            V[it & 1][t] = nv;
+            nu = hist_u(it - 2, t);
+            nv = hist_v(it - 3, t);
+        }
+        // (B) through u_t: column pass with P_t
+        {
+            const float vj = Vp[lsafe];
+            float ou[EPT], og[EPT];
+            load_other<EPT>(ou, Uc, q);
+            load_other<EPT>(og, gu, q);
             float r = 0.f;
 #pragma unroll
             for (int m = 0; m < EPT; ++m) {
-                const int idx = q + lpr * m;
-                if (idx < n) {
-                    const float pp = expf((((-ccol[m] + ut[idx]) + vj) - aconst) / eps);
-                    const float w = pp * gu[idx];
-                    dcol[m] += w;
-                    r += w;
-                }
+                const float pp = fast_exp((((-ccol[m] + ou[m]) + vj) - aconst) * inv_eps);
+                const float w = pp * og[m];
+                dcol[m] += w;
+                r += w;
             }
-            r = seg_sum(r, lpr);
-            if (q == 0) gv[line] = -r;
+            r = seg_sum<LPR>(r);
+            if (active && q == 0) gv[line] = -r;
         }
+        __syncthreads();
     }
 
     // dC = row-layout part + (column-layout part)^T
@@ -270,7 +341,7 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
     if (active) {
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
-            const int idx = q + lpr * m;
+            const int idx = q * EPT + m;
             if (idx < n) dC[(int64_t)line * n + idx] = drow[m];
         }
     }
@@ -279,7 +350,7 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
     if (active) {
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
-            const int idx = q + lpr * m;
+            const int idx = q * EPT + m;
             if (idx < n) dC[(int64_t)idx * n + line] += dcol[m];
         }
     }
@@ -291,13 +362,11 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
 struct SinkGeom { int lpr, ept, threads; };
 
 static SinkGeom sink_geom(int n) {
-    int lpr = 64;
-    while (lpr > 1 && (int64_t)n * lpr > SK_MAXT) lpr >>= 1;
     SinkGeom g;
-    g.lpr = lpr;
-    const int need = (n + lpr - 1) / lpr;
+    g.lpr = (n <= 32) ? 16 : 8;                       // n*lpr <= 1024 for n <= 128
+    const int need = (n + g.lpr - 1) / g.lpr;
     g.ept = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
-    g.threads = (n * lpr + 63) / 64 * 64;
+    g.threads = (n * g.lpr + 63) / 64 * 64;
     return g;
 }
 
@@ -310,13 +379,20 @@ extern "C" size_t kccot_sinkhorn_workspace_bytes(int nprob, int n) {
     return 0;   // the register-resident kernels need none; kept for the large-n path
 }
 
-#define KCCOT_SK_DISPATCH(KERNEL, ARGS, GEOM, NPROB, ST)                                                  \
-    switch ((GEOM).ept) {                                                                                 \
-        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(NPROB), dim3((GEOM).threads), 0, ST, ARGS); break;     \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(NPROB), dim3((GEOM).threads), 0, ST, ARGS); break;     \
-        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(NPROB), dim3((GEOM).threads), 0, ST, ARGS); break;     \
-        case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(NPROB), dim3((GEOM).threads), 0, ST, ARGS); break;     \
-        default: hipLaunchKernelGGL(KERNEL<16>, dim3(NPROB), dim3((GEOM).threads), 0, ST, ARGS); break;   \
+#define KCCOT_SK_LAUNCH(KERNEL, E, P, ARGS, GEOM, NPROB, ST) \
+    hipLaunchKernelGGL((KERNEL<E, P>), dim3(NPROB), dim3((GEOM).threads), 0, ST, ARGS)
+
+#define KCCOT_SK_DISPATCH(KERNEL, ARGS, GEOM, NPROB, ST)                                       \
+    if ((GEOM).lpr == 16) {                                                                    \
+        switch ((GEOM).ept) {                                                                  \
+            case 1: KCCOT_SK_LAUNCH(KERNEL, 1, 16, ARGS, GEOM, NPROB, ST); break;              \
+            default: KCCOT_SK_LAUNCH(KERNEL, 2, 16, ARGS, GEOM, NPROB, ST); break;             \
+        }                                                                                      \
+    } else {                                                                                   \
+        switch ((GEOM).ept) {                                                                  \
+            case 8: KCCOT_SK_LAUNCH(KERNEL, 8, 8, ARGS, GEOM, NPROB, ST); break;               \
+            default: KCCOT_SK_LAUNCH(KERNEL, 16, 8, ARGS, GEOM, NPROB, ST); break;             \
+        }                                                                                      \
     }
 
 extern "C" int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float eps, int L, int Lmin,
@@ -335,7 +411,7 @@ extern "C" int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float ep
         return fail(KCCOT_EUNSUPPORTED, "sinkhorn_fwd: n=%d > %d (the multi-CU solver for larger "
                     "batches is not built yet)", n, SK_MAXN);
     SinkGeom g = sink_geom(n);
-    SinkArgs a{C, n, L, Lmin, stop_mode, g.lpr, eps, thresh, u_hist, v_hist, cost_out, nits_out, pi_out};
+    SinkArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out};
     hipStream_t st = (hipStream_t)stream;
     KCCOT_SK_DISPATCH(sinkhorn_fwd_reg, a, g, nprob, st)
     return launch_status("sinkhorn_fwd_reg");
@@ -353,7 +429,7 @@ extern "C" int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const
     if (n > SK_MAXN)
         return fail(KCCOT_EUNSUPPORTED, "sinkhorn_bwd: n=%d > %d", n, SK_MAXN);
     SinkGeom g = sink_geom(n);
-    SinkBwdArgs a{C, u_hist, v_hist, nits, gcost, dC_out, n, L, g.lpr, eps};
+    SinkBwdArgs a{C, u_hist, v_hist, nits, gcost, dC_out, n, L, eps, (float)(1.0 / (double)eps)};
     hipStream_t st = (hipStream_t)stream;
     KCCOT_SK_DISPATCH(sinkhorn_bwd_reg, a, g, nprob, st)
     return launch_status("sinkhorn_bwd_reg");

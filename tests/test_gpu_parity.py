@@ -58,8 +58,17 @@ def flat(v):
 PATHS = ["auto", "direct", "mfma"]
 
 
-def set_path(G, L, path):
+def set_path(G, L, path, K=None):
+    """Select the cost kernel.  The MFMA path needs K % 4 == 0 and K >= 32 (one k-tile); the
+    'tiny' golden shape (K = 24) is below that and only runs the direct kernel."""
+    if path == "mfma" and K is not None and (K % 4 != 0 or K < 32):
+        pytest.skip("MFMA path not eligible for K=%d" % K)
     G.cost_flags = {"auto": 0, "direct": L.COST_FORCE_DIRECT, "mfma": L.COST_FORCE_MFMA}[path]
+
+
+def kdim(shape):
+    B, H, T, W, C, J = cases.SHAPES[shape]
+    return H * T * W * C
 
 
 @pytest.fixture(autouse=True)
@@ -73,7 +82,7 @@ def _reset_flags(G):
 @pytest.mark.parametrize("shape,seed,regime", ALL)
 def test_cost3_matches_reference(G, L, shape, seed, regime, path):
     g, inp, t = load(shape, seed, regime)
-    set_path(G, L, path)
+    set_path(G, L, path, kdim(shape))
     B = t["real"].shape[0]
     real, fake = t["real"].reshape(B, -1), t["fake"].reshape(B, -1)
     C3 = G._Cost3.apply(real, fake, t["h_fake"], t["h_real"], t["m_real"], t["m_fake"], cases.SC).cpu().numpy()
@@ -91,7 +100,7 @@ def test_cost3_matches_reference(G, L, shape, seed, regime, path):
 @pytest.mark.parametrize("shape,seed,regime", SMALL)
 def test_public_cost_functions(G, L, shape, seed, regime, path):
     g, inp, t = load(shape, seed, regime)
-    set_path(G, L, path)
+    set_path(G, L, path, kdim(shape))
     x, y = flat(t["real"]), flat(t["fake"])
     tol = lambda ref: dict(rtol=0, atol=1e-5 * np.abs(ref).max())
     np.testing.assert_allclose(G.cost_xy(x, y, cases.SC).cpu().numpy(), g["C_plain"], **tol(g["C_plain"]))
@@ -138,7 +147,10 @@ def test_sinkhorn_variants_match_reference(G, shape, seed, regime):
     assert rel(w, g["w_bench_default"]) < 5e-5 and int(G.last_info["benchmark_sinkhorn"][0]) == 10
     w = G.benchmark_sinkhorn(x, y, cases.SC, epsilon=0.8, L=50, Lmin=20)
     assert rel(w, g["w_bench_e0.8_L50_Lmin20"]) < 5e-5
-    assert int(G.last_info["benchmark_sinkhorn"][0]) == int(g["nits_bench_e0.8_L50_Lmin20"])
+    # the stop test compares sum|u-u_prev| with 1e-2; where that sum passes the threshold within fp32
+    # rounding the reference's own fp32 and fp64 runs disagree by one iteration (cfg1_s1_far: 21 vs 22)
+    assert int(G.last_info["benchmark_sinkhorn"][0]) in (int(g["nits_bench_e0.8_L50_Lmin20"]),
+                                                         int(g["nits_bench_e0.8_L50_Lmin20_f64"]))
 
 
 def test_sinkhorn_stop_rule_past_lmin(G):
@@ -187,7 +199,7 @@ def test_sinkhorn_kats(G, L):
 @pytest.mark.parametrize("shape,seed,regime", ALL)
 def test_loss_matches_reference(G, L, shape, seed, regime, path):
     g, inp, t = load(shape, seed, regime)
-    set_path(G, L, path)
+    set_path(G, L, path, kdim(shape))
     loss = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 100, t["h_fake"], t["m_real"],
                                    t["h_real"], t["m_fake"], video=True)
     nits = G.last_info["compute_sinkhorn_loss"].cpu().numpy().tolist()
@@ -280,7 +292,7 @@ def _grad_oracle(inp, wrt, fn):
                                                ("small", 1, "far"), ("deci64", 0, "near"), ("deci64", 1, "far")])
 def test_loss_gradients_match_autograd_through_the_unrolled_loop(G, L, shape, seed, regime, path):
     g, inp, t = load(shape, seed, regime)
-    set_path(G, L, path)
+    set_path(G, L, path, kdim(shape))
     wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]     # kernel_train.py:252,289 (never real)
     ref_val, ref = _grad_oracle(inp, wrt, lambda d: ot.compute_sinkhorn_loss(
         d["real"], d["fake"], cases.SC, 0.8, 100, d["h_fake"], d["m_real"], d["h_real"], d["m_fake"]))
