@@ -124,6 +124,12 @@ int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const float* v_h
                            const float* gcost, float* dC_out,
                            void* ws, size_t ws_bytes, kccot_stream_t stream);
 
+/* Mixed Sinkhorn divergence (gan_utils.py:225): loss = 2*cost3[0] - cost3[1] - cost3[2] for
+ * cost3 = [W(real,fake), W(real,real), W(fake,fake)], and its backward gcost3 = gloss*[2,-1,-1].
+ * All arguments are device pointers (one launch each, no host round trip). */
+int kccot_mixed_divergence_fwd_f32(const float* cost3, float* loss_out, kccot_stream_t stream);
+int kccot_mixed_divergence_bwd_f32(const float* gloss, float* gcost3_out, kccot_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Martingale penalty.  Replaces scale_invariante_martingale_regularization (gan_utils.py:179-201):
  *   pM = lam * sc * sum_{t<T-1,q} | (1/B) sum_b (M[b,t+1,q]-M[b,t,q]) / (std_{b,t}(M[:,:,q]) + 1e-6) |

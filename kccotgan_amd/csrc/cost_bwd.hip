@@ -18,51 +18,53 @@ enum CoeffMode { CO_LOSS3_DFAKE = 0, CO_DX = 1, CO_DY = 2, CO_SAME = 3 };
 
 // Wt is [R][Bout] (stack-row major) so that one output row block reads contiguous scalars.
 // R = n1 + n2 stack rows: first the n1 rows of src1, then the n2 rows of src2.
+// One block per output row m: thread r writes Wt[r][m]; the row / column sums that sit on the
+// diagonal are a block reduction (no serial loop).
 __global__ __launch_bounds__(256) void build_coeffs(int mode, const float* __restrict__ g, const float* __restrict__ g2,
                                                     int Bx, int By, float sc, float* __restrict__ Wt) {
     // g: [Bx,By] (LOSS3: gxy [B,B]); g2: LOSS3 only: gyy [B,B]
+    __shared__ float red[16];
     const int Bout = (mode == CO_DY) ? By : (mode == CO_LOSS3_DFAKE ? By : Bx);
     const int R = (mode == CO_SAME) ? Bx : Bx + By;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= R * Bout) return;
-    const int r = e / Bout, m = e % Bout;
+    const int m = blockIdx.x;
     const float two_sc = 2.f * sc;
-    float w = 0.f;
-    if (mode == CO_LOSS3_DFAKE) {
-        const int B = Bx;
-        if (r < B) {
-            w = -two_sc * g[(int64_t)r * B + m];                       // -2sc gxy[r][m] * x_r
+    // diagonal sum for this m
+    float part = 0.f;
+    for (int i = threadIdx.x; i < (Bx > By ? Bx : By); i += blockDim.x) {
+        if (mode == CO_LOSS3_DFAKE) {
+            if (i < Bx) part += g[(int64_t)i * Bx + m] + g2[(int64_t)m * Bx + i] + g2[(int64_t)i * Bx + m];
+        } else if (mode == CO_DX) {
+            if (i < By) part += g[(int64_t)m * By + i];
+        } else if (mode == CO_DY) {
+            if (i < Bx) part += g[(int64_t)i * By + m];
         } else {
-            const int rr = r - B;
-            w = -two_sc * (g2[(int64_t)m * B + rr] + g2[(int64_t)rr * B + m]);
-            if (rr == m) {
-                float d = 0.f;
-                for (int i = 0; i < B; ++i)
-                    d += g[(int64_t)i * B + m] + g2[(int64_t)m * B + i] + g2[(int64_t)i * B + m];
-                w += two_sc * d;
-            }
-        }
-    } else if (mode == CO_DX) {        // out rows = x rows
-        if (r < Bx) {
-            if (r == m) { float d = 0.f; for (int j = 0; j < By; ++j) d += g[(int64_t)m * By + j]; w = two_sc * d; }
-        } else {
-            w = -two_sc * g[(int64_t)m * By + (r - Bx)];
-        }
-    } else if (mode == CO_DY) {        // out rows = y rows
-        if (r < Bx) {
-            w = -two_sc * g[(int64_t)r * By + m];
-        } else if (r - Bx == m) {
-            float d = 0.f; for (int i = 0; i < Bx; ++i) d += g[(int64_t)i * By + m]; w = two_sc * d;
-        }
-    } else {                           // CO_SAME: x is y
-        w = -two_sc * (g[(int64_t)m * Bx + r] + g[(int64_t)r * Bx + m]);
-        if (r == m) {
-            float d = 0.f;
-            for (int i = 0; i < Bx; ++i) d += g[(int64_t)m * Bx + i] + g[(int64_t)i * Bx + m];
-            w += two_sc * d;
+            if (i < Bx) part += g[(int64_t)m * Bx + i] + g[(int64_t)i * Bx + m];
         }
     }
-    Wt[e] = w;
+    const float d = block_sum(part, red);
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        float w = 0.f;
+        if (mode == CO_LOSS3_DFAKE) {
+            const int B = Bx;
+            if (r < B) {
+                w = -two_sc * g[(int64_t)r * B + m];                       // -2sc gxy[r][m] * x_r
+            } else {
+                const int rr = r - B;
+                w = -two_sc * (g2[(int64_t)m * B + rr] + g2[(int64_t)rr * B + m]);
+                if (rr == m) w += two_sc * d;
+            }
+        } else if (mode == CO_DX) {        // out rows = x rows
+            if (r < Bx) w = (r == m) ? two_sc * d : 0.f;
+            else w = -two_sc * g[(int64_t)m * By + (r - Bx)];
+        } else if (mode == CO_DY) {        // out rows = y rows
+            if (r < Bx) w = -two_sc * g[(int64_t)r * By + m];
+            else w = (r - Bx == m) ? two_sc * d : 0.f;
+        } else {                           // CO_SAME: x is y
+            w = -two_sc * (g[(int64_t)m * Bx + r] + g[(int64_t)r * Bx + m]);
+            if (r == m) w += two_sc * d;
+        }
+        Wt[(int64_t)r * Bout + m] = w;
+    }
 }
 
 // out[m0+mm][k] = sum_r Wt[r][m0+mm] * Z_r[k];  one column k per thread, MB output rows per block row.
@@ -183,6 +185,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int AM_COLS = 64;
 constexpr int AM_ROWS = 128;
 
+template <int NSTEPS>
 __global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict__ Wt, const float* __restrict__ src1,
                                                          int n1, const float* __restrict__ src2, int n2, int Bout,
                                                          int64_t K, int64_t ntiles, float* __restrict__ out) {
@@ -190,15 +193,14 @@ __global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int mblk = wave & 1, cblk = wave >> 1;
-    const int R = n1 + n2;
-    const int nsteps = (R + 1) / 2;
+    const int R = n1 + n2;   // <= 2 * NSTEPS
 
     // W fragments: afrag[s] = W[m = 32*mblk + (lane&31)][r = 2s + (lane>>5)]
-    float afrag[AM_ROWS / 2];
+    float afrag[NSTEPS];
     {
         const int m = 32 * mblk + (lane & 31);
 #pragma unroll
-        for (int s = 0; s < AM_ROWS / 2; ++s) {
+        for (int s = 0; s < NSTEPS; ++s) {
             const int r = 2 * s + (lane >> 5);
             afrag[s] = (r < R && m < Bout) ? Wt[(int64_t)r * Bout + m] : 0.f;
         }
@@ -233,9 +235,8 @@ __global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* zb = zs + (lane >> 5) * AM_COLS + 32 * cblk + (lane & 31);
 #pragma unroll
-        for (int s = 0; s < AM_ROWS / 2; ++s) {
-            if (s < nsteps) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[s], zb[2 * s * AM_COLS], acc, 0, 0, 0);
-        }
+        for (int s = 0; s < NSTEPS; ++s)   // branch-free: the LDS reads pipeline ahead of the MFMA chain
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[s], zb[2 * s * AM_COLS], acc, 0, 0, 0);
         __syncthreads();
         const int64_t col = tile * AM_COLS + 32 * cblk + (lane & 31);
         if (col < K) {
@@ -254,9 +255,12 @@ static int launch_apply(const float* Wt, const float* s1, int n1, const float* s
     const bool al = (K % 4 == 0) && ((uintptr_t)s1 % 16 == 0) && (n2 == 0 || (uintptr_t)s2 % 16 == 0);
     if (al && n1 + n2 <= AM_ROWS && Bout <= 64) {
         const int64_t ntiles = (K + AM_COLS - 1) / AM_COLS;
-        const unsigned grid = (unsigned)(ntiles < 768 ? ntiles : 768);   // 3 workgroups per CU
-        hipLaunchKernelGGL(apply_coeffs_mfma, dim3(grid), dim3(256), 0, st, Wt, s1, n1, s2 ? s2 : s1, n2, Bout, K,
-                           ntiles, out);
+        const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);   // 2 workgroups per CU (VGPR-limited)
+        const int R = n1 + n2;
+        const float* s2p = s2 ? s2 : s1;
+        if (R > 64) hipLaunchKernelGGL(apply_coeffs_mfma<64>, dim3(grid), dim3(256), 0, st, Wt, s1, n1, s2p, n2, Bout, K, ntiles, out);
+        else if (R > 32) hipLaunchKernelGGL(apply_coeffs_mfma<32>, dim3(grid), dim3(256), 0, st, Wt, s1, n1, s2p, n2, Bout, K, ntiles, out);
+        else hipLaunchKernelGGL(apply_coeffs_mfma<16>, dim3(grid), dim3(256), 0, st, Wt, s1, n1, s2p, n2, Bout, K, ntiles, out);
         return launch_status("apply_coeffs_mfma");
     }
     const unsigned gx = (unsigned)((K + 255) / 256);
@@ -296,7 +300,7 @@ extern "C" int kccot_pairwise_cost3_bwd_f32(const float* g3, const float* real, 
         if (!ws || ws_bytes < need)
             return fail(KCCOT_EWORKSPACE, "pairwise_cost3_bwd: workspace %zu < required %zu", ws_bytes, need);
         float* Wt = static_cast<float*>(ws);
-        hipLaunchKernelGGL(build_coeffs, dim3((2 * B * B + 255) / 256), dim3(256), 0, st, (int)CO_LOSS3_DFAKE,
+        hipLaunchKernelGGL(build_coeffs, dim3(B), dim3(256), 0, st, (int)CO_LOSS3_DFAKE,
                            gxy, gyy, B, B, sc, Wt);
         if ((rc = launch_status("build_coeffs"))) return rc;
         if ((rc = launch_apply(Wt, real, B, fake, B, B, K, dfake, st))) return rc;
@@ -340,21 +344,20 @@ extern "C" int kccot_pairwise_cost_bwd_f32(const float* g, const float* x, const
     float* W2 = reinterpret_cast<float*>(static_cast<char*>(ws) + kccot_pairwise_cost_bwd_workspace_bytes(Bx, By) / 2);
     if (same) {
         if (dx) {
-            hipLaunchKernelGGL(build_coeffs, dim3((Bx * Bx + 255) / 256), dim3(256), 0, st, (int)CO_SAME, g,
+            hipLaunchKernelGGL(build_coeffs, dim3(Bx), dim3(256), 0, st, (int)CO_SAME, g,
                                (const float*)nullptr, Bx, Bx, sc, W1);
             if ((rc = launch_status("build_coeffs"))) return rc;
             if ((rc = launch_apply(W1, x, Bx, x, 0, Bx, K, dx, st))) return rc;
         }
     } else {
-        const int R = Bx + By;
         if (dx) {
-            hipLaunchKernelGGL(build_coeffs, dim3((R * Bx + 255) / 256), dim3(256), 0, st, (int)CO_DX, g,
+            hipLaunchKernelGGL(build_coeffs, dim3(Bx), dim3(256), 0, st, (int)CO_DX, g,
                                (const float*)nullptr, Bx, By, sc, W1);
             if ((rc = launch_status("build_coeffs"))) return rc;
             if ((rc = launch_apply(W1, x, Bx, y, By, Bx, K, dx, st))) return rc;
         }
         if (dy) {
-            hipLaunchKernelGGL(build_coeffs, dim3((R * By + 255) / 256), dim3(256), 0, st, (int)CO_DY, g,
+            hipLaunchKernelGGL(build_coeffs, dim3(By), dim3(256), 0, st, (int)CO_DY, g,
                                (const float*)nullptr, Bx, By, sc, W2);
             if ((rc = launch_status("build_coeffs"))) return rc;
             if ((rc = launch_apply(W2, x, Bx, y, By, By, K, dy, st))) return rc;

@@ -37,10 +37,11 @@ struct CostPlan {
 //   sum_{t<T-1} sum_q h[i0+ti,t,q] * (M[j0+tj,t+1,q] - M[j0+tj,t,q])            (gan_utils.py:34-38)
 // With k = t*J + q running over (T-1)*J values this is a [16 x KK] x [KK x 16] product of the
 // flattened h rows and first differences of the flattened M rows (M[k+J] - M[k]); both are
-// staged through LDS in 64-wide k chunks so that global reads are coalesced.
-// sh, sm: 16*65 floats of LDS each.  Every thread of the block must call it.
+// staged through LDS in CAUSAL_KC-wide k chunks ((T-1)*J = 232 fits in one at the default T = 30,
+// J = 8) so that global reads are coalesced and all issued before the single wait.
+// sh, sm: CAUSAL_TILE*CAUSAL_PITCH floats of LDS each.  Every thread of the block must call it.
 constexpr int CAUSAL_TILE = 16;
-constexpr int CAUSAL_KC = 64;
+constexpr int CAUSAL_KC = 256;
 constexpr int CAUSAL_PITCH = CAUSAL_KC + 1;
 
 __device__ __forceinline__ float causal_tile16(const float* __restrict__ h, const float* __restrict__ M, int i0,
@@ -50,8 +51,8 @@ __device__ __forceinline__ float causal_tile16(const float* __restrict__ h, cons
     float tot = 0.f;
     for (int k0 = 0; k0 < KK; k0 += CAUSAL_KC) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int e = t + 256 * m, row = e >> 6, kk = e & 63, k = k0 + kk;
+        for (int m = 0; m < CAUSAL_TILE; ++m) {
+            const int row = m, kk = t, k = k0 + kk;
             const bool kok = k < KK;
             sh[row * CAUSAL_PITCH + kk] = (kok && i0 + row < Bx) ? h[(int64_t)(i0 + row) * TJ + k] : 0.f;
             float d = 0.f;

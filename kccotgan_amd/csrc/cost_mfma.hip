@@ -105,6 +105,7 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ row, int64_t k, 
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A4.z, B4.z, ACC, 0, 0, 0);     \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A4.w, B4.w, ACC, 0, 0, 0);
 
+template <bool FULL10>
 __global__ __launch_bounds__(256) void gram128_partial(GramArgs ga) {
     __shared__ __attribute__((aligned(16))) float zs[GRAM_ROWS * GPITCH];
 
@@ -156,22 +157,43 @@ __global__ __launch_bounds__(256) void gram128_partial(GramArgs ga) {
             v2 = ld4(p2, kn + c4, kend, ok2);
             v3 = ld4(p3, kn + c4, kend, ok3);
         }
+        if constexpr (FULL10) {
+            // all ten sub-tiles: entries 0 and 1 over the whole k-tile, entry 2 over its half --
+            // straight-line, so the scheduler can hoist every ds_read_b128 above the MFMA chain
+            const int half = (wave & 1) * 16;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // four groups of 8 k
-            if (ww.n > 0 && g >= ww.lo[0] && g < ww.hi[0]) {
-                const float4 A = *reinterpret_cast<const float4*>(&zs[arow0 + 8 * g]);
-                const float4 B = *reinterpret_cast<const float4*>(&zs[brow0 + 8 * g]);
-                KCCOT_MFMA4(acc0, A, B)
+            for (int g = 0; g < 4; ++g) {
+                const float4 A0 = *reinterpret_cast<const float4*>(&zs[arow0 + 8 * g]);
+                const float4 B0 = *reinterpret_cast<const float4*>(&zs[brow0 + 8 * g]);
+                const float4 A1 = *reinterpret_cast<const float4*>(&zs[arow1 + 8 * g]);
+                const float4 B1 = *reinterpret_cast<const float4*>(&zs[brow1 + 8 * g]);
+                KCCOT_MFMA4(acc0, A0, B0)
+                KCCOT_MFMA4(acc1, A1, B1)
             }
-            if (ww.n > 1 && g >= ww.lo[1] && g < ww.hi[1]) {
-                const float4 A = *reinterpret_cast<const float4*>(&zs[arow1 + 8 * g]);
-                const float4 B = *reinterpret_cast<const float4*>(&zs[brow1 + 8 * g]);
-                KCCOT_MFMA4(acc1, A, B)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 A2 = *reinterpret_cast<const float4*>(&zs[arow2 + half + 8 * g]);
+                const float4 B2 = *reinterpret_cast<const float4*>(&zs[brow2 + half + 8 * g]);
+                KCCOT_MFMA4(acc2, A2, B2)
             }
-            if (ww.n > 2 && g >= ww.lo[2] && g < ww.hi[2]) {
-                const float4 A = *reinterpret_cast<const float4*>(&zs[arow2 + 8 * g]);
-                const float4 B = *reinterpret_cast<const float4*>(&zs[brow2 + 8 * g]);
-                KCCOT_MFMA4(acc2, A, B)
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // four groups of 8 k
+                if (ww.n > 0 && g >= ww.lo[0] && g < ww.hi[0]) {
+                    const float4 A = *reinterpret_cast<const float4*>(&zs[arow0 + 8 * g]);
+                    const float4 B = *reinterpret_cast<const float4*>(&zs[brow0 + 8 * g]);
+                    KCCOT_MFMA4(acc0, A, B)
+                }
+                if (ww.n > 1 && g >= ww.lo[1] && g < ww.hi[1]) {
+                    const float4 A = *reinterpret_cast<const float4*>(&zs[arow1 + 8 * g]);
+                    const float4 B = *reinterpret_cast<const float4*>(&zs[brow1 + 8 * g]);
+                    KCCOT_MFMA4(acc1, A, B)
+                }
+                if (ww.n > 2 && g >= ww.lo[2] && g < ww.hi[2]) {
+                    const float4 A = *reinterpret_cast<const float4*>(&zs[arow2 + 8 * g]);
+                    const float4 B = *reinterpret_cast<const float4*>(&zs[brow2 + 8 * g]);
+                    KCCOT_MFMA4(acc2, A, B)
+                }
             }
         }
         __syncthreads();
@@ -212,10 +234,19 @@ __global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gp
     double s = 0.0;
     if (need) {
         const float* p = gpart + e;
-        for (int c = grp; c < nchunk; c += 16) {
-            const float* pc = p + (int64_t)c * GRAM_SLABS * 1024;
-            s += (double)pc[0];
-            if (split) s += (double)pc[2048];
+        const int64_t cs = (int64_t)GRAM_SLABS * 1024;
+        int c = grp;
+        // four chunks per trip: eight independent loads in flight, added in chunk order
+        for (; c + 48 < nchunk; c += 64) {
+            const float a0 = p[c * cs], a1 = p[(c + 16) * cs], a2 = p[(c + 32) * cs], a3 = p[(c + 48) * cs];
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+            if (split) { b0 = p[c * cs + 2048]; b1 = p[(c + 16) * cs + 2048]; b2 = p[(c + 32) * cs + 2048]; b3 = p[(c + 48) * cs + 2048]; }
+            s += (double)a0; s += (double)b0; s += (double)a1; s += (double)b1;
+            s += (double)a2; s += (double)b2; s += (double)a3; s += (double)b3;
+        }
+        for (; c < nchunk; c += 16) {
+            s += (double)p[c * cs];
+            if (split) s += (double)p[c * cs + 2048];
         }
     }
     part[grp][el] = s;
@@ -306,7 +337,7 @@ bool gram_preferred(const CostBatch& cb, int64_t K, bool loss3) {
 static int gram_target_wgs() {
     const char* e = getenv("KCCOT_GRAM_WGS");   // tuning knob (bench sweeps)
     int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 512;
+    return v > 0 ? v : 256;
 }
 
 GramPlan plan_gram(int64_t K) {
@@ -373,7 +404,8 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     ga.K = K; ga.chunk = pl.chunk;
     ga.gpart = static_cast<float*>(ws);
     double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.gpart_bytes);
-    hipLaunchKernelGGL(gram128_partial, dim3(pl.nchunk), dim3(256), 0, st, ga);
+    if (ga.mask == 0x3FFu) hipLaunchKernelGGL(gram128_partial<true>, dim3(pl.nchunk), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL(gram128_partial<false>, dim3(pl.nchunk), dim3(256), 0, st, ga);
     int rc = launch_status("gram128_partial");
     if (rc || partial_only) return rc;
     hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 64), dim3(1024), 0, st,

@@ -20,6 +20,7 @@
 // max shift, so the relative error of the sum stays at the 1e-7 level.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace kccot {
 
@@ -33,12 +34,17 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
+// max(v, dpp(v)) in ONE instruction.  fmaxf() on a DPP move costs mov + canonicalise + max; the
+// values here are never NaN-signalling, so the bare v_max_f32_dpp is exact.  The s_nop covers the
+// VALU-write -> DPP-read hazard (2 wait states) that hipcc does not pad inside an asm statement.
+#define KCCOT_DPP_MAX(V, CTRL)                                                                          \
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(V) : "v"(V))
 template <int LPR>
 __device__ __forceinline__ float seg_max(float v) {
-    if (LPR >= 2) v = fmaxf(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
-    if (LPR >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
-    if (LPR >= 8) v = fmaxf(v, dpp_mov<0x141>(v));   // row_half_mirror
-    if (LPR >= 16) v = fmaxf(v, dpp_mov<0x140>(v));  // row_mirror
+    if (LPR >= 2) KCCOT_DPP_MAX(v, "quad_perm:[1,0,3,2]");
+    if (LPR >= 4) KCCOT_DPP_MAX(v, "quad_perm:[2,3,0,1]");
+    if (LPR >= 8) KCCOT_DPP_MAX(v, "row_half_mirror");
+    if (LPR >= 16) KCCOT_DPP_MAX(v, "row_mirror");
     return v;
 }
 template <int LPR>
@@ -97,10 +103,15 @@ __device__ __forceinline__ float half_step(const float (&c)[EPT], float self, co
     mx = seg_max<LPR>(mx);
     // tf.reduce_logsumexp: a non-finite max is replaced by 0
     const float shift = (mx > -INFINITY && mx < INFINITY) ? mx : 0.f;
-    float s = 0.f;
+    float e[EPT];
 #pragma unroll
-    for (int m = 0; m < EPT; ++m) s += __builtin_amdgcn_exp2f((x[m] - shift) * LOG2E);
-    s = seg_sum<LPR>(s);
+    for (int m = 0; m < EPT; ++m) e[m] = __builtin_amdgcn_exp2f((x[m] - shift) * LOG2E);
+    // pairwise tree: log2(EPT) dependent adds instead of EPT
+#pragma unroll
+    for (int w = 1; w < EPT; w *= 2)
+#pragma unroll
+        for (int m = 0; m + w < EPT; m += 2 * w) e[m] += e[m + w];
+    const float s = seg_sum<LPR>(e[0]);
     const float lse = fast_log(s) + shift;
     return eps * (log_w - lse) + self;   // gan_utils.py:154,156
 }
@@ -356,6 +367,17 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
     }
 }
 
+// gan_utils.py:225: loss = 2.0 * loss_xy - loss_xx - loss_yy, evaluated left to right in fp32
+__global__ void mixed_divergence_fwd(const float* __restrict__ cost3, float* __restrict__ loss) {
+    if (threadIdx.x == 0) loss[0] = (2.0f * cost3[0] - cost3[1]) - cost3[2];
+}
+__global__ void mixed_divergence_bwd(const float* __restrict__ gloss, float* __restrict__ gcost3) {
+    if (threadIdx.x == 0) {
+        const float g = gloss[0];
+        gcost3[0] = 2.0f * g; gcost3[1] = -g; gcost3[2] = -g;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -364,6 +386,12 @@ struct SinkGeom { int lpr, ept, threads; };
 static SinkGeom sink_geom(int n) {
     SinkGeom g;
     g.lpr = (n <= 32) ? 16 : 8;                       // n*lpr <= 1024 for n <= 128
+    if (n > 32 && n <= 64) {
+        // tuning knob for the configs[1] size: 4, 8 or 16 lanes per line (256 / 512 / 1024 threads)
+        const char* e = getenv("KCCOT_SK_LPR");
+        const int v = e ? atoi(e) : 0;
+        if (v == 4 || v == 8 || v == 16) g.lpr = v;
+    }
     const int need = (n + g.lpr - 1) / g.lpr;
     g.ept = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
     g.threads = (n * g.lpr + 63) / 64 * 64;
@@ -386,8 +414,11 @@ extern "C" size_t kccot_sinkhorn_workspace_bytes(int nprob, int n) {
     if ((GEOM).lpr == 16) {                                                                    \
         switch ((GEOM).ept) {                                                                  \
             case 1: KCCOT_SK_LAUNCH(KERNEL, 1, 16, ARGS, GEOM, NPROB, ST); break;              \
-            default: KCCOT_SK_LAUNCH(KERNEL, 2, 16, ARGS, GEOM, NPROB, ST); break;             \
+            case 2: KCCOT_SK_LAUNCH(KERNEL, 2, 16, ARGS, GEOM, NPROB, ST); break;              \
+            default: KCCOT_SK_LAUNCH(KERNEL, 4, 16, ARGS, GEOM, NPROB, ST); break;             \
         }                                                                                      \
+    } else if ((GEOM).lpr == 4) {                                                              \
+        KCCOT_SK_LAUNCH(KERNEL, 16, 4, ARGS, GEOM, NPROB, ST);                                 \
     } else {                                                                                   \
         switch ((GEOM).ept) {                                                                  \
             case 8: KCCOT_SK_LAUNCH(KERNEL, 8, 8, ARGS, GEOM, NPROB, ST); break;               \
@@ -433,4 +464,16 @@ extern "C" int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const
     hipStream_t st = (hipStream_t)stream;
     KCCOT_SK_DISPATCH(sinkhorn_bwd_reg, a, g, nprob, st)
     return launch_status("sinkhorn_bwd_reg");
+}
+
+extern "C" int kccot_mixed_divergence_fwd_f32(const float* cost3, float* loss_out, kccot_stream_t stream) {
+    if (!cost3 || !loss_out) return fail(KCCOT_EINVAL, "mixed_divergence_fwd: null pointer");
+    hipLaunchKernelGGL(mixed_divergence_fwd, dim3(1), dim3(64), 0, (hipStream_t)stream, cost3, loss_out);
+    return launch_status("mixed_divergence_fwd");
+}
+
+extern "C" int kccot_mixed_divergence_bwd_f32(const float* gloss, float* gcost3_out, kccot_stream_t stream) {
+    if (!gloss || !gcost3_out) return fail(KCCOT_EINVAL, "mixed_divergence_bwd: null pointer");
+    hipLaunchKernelGGL(mixed_divergence_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, gloss, gcost3_out);
+    return launch_status("mixed_divergence_bwd");
 }

@@ -190,6 +190,23 @@ class _Sinkhorn(torch.autograd.Function):
         return dC, None, None, None, None, None
 
 
+class _MixedDivergence(torch.autograd.Function):
+    """loss = 2*W_xy - W_xx - W_yy (gan_utils.py:225) as one launch each way."""
+
+    @staticmethod
+    def forward(ctx, cost3):
+        loss = torch.empty((1,), dtype=torch.float32, device=cost3.device)
+        check(lib.kccot_mixed_divergence_fwd_f32(ptr(cost3), ptr(loss), stream_of(cost3)), "mixed_divergence_fwd")
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.reshape(1).contiguous().float()
+        gc = torch.empty((3,), dtype=torch.float32, device=g.device)
+        check(lib.kccot_mixed_divergence_bwd_f32(ptr(g), ptr(gc), stream_of(g)), "mixed_divergence_bwd")
+        return gc
+
+
 class _Martingale(torch.autograd.Function):
     @staticmethod
     def forward(ctx, M, lam, sc):
@@ -280,4 +297,4 @@ def compute_sinkhorn_loss(f_real, f_fake, scaling_coef, sinkhorn_eps, sinkhorn_l
     real, fake = _flat2(f_real), _flat2(f_fake)
     C3 = _Cost3.apply(real, fake, _feat(h_fake), _feat(h_real), _feat(m_real), _feat(m_fake), float(scaling_coef))
     w = _Sinkhorn.apply(C3, eps, L, _LMIN, _lib.STOP_COUNT, "compute_sinkhorn_loss")   # [xy, xx, yy]
-    return 2.0 * w[0] - w[1] - w[2]
+    return _MixedDivergence.apply(w)

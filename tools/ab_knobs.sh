@@ -1,0 +1,21 @@
+#!/bin/bash
+# A/B of the tuning knobs on one box, one process per setting (same device): prints one line each.
+set -o pipefail
+OUT=gpurun_out/${1:-ab}
+mkdir -p "$OUT"
+run() {
+    local tag=$1; shift
+    env "$@" timeout -k 10 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/$tag.json" 2> "$OUT/$tag.err" || { echo "$tag failed"; tail -5 "$OUT/$tag.err"; return 1; }
+    python - "$tag" "$OUT/$tag.json" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+r=d["roofline"]
+print("%-22s ms/step %.4f  cost-kernel %.1f us  cost-stage %.1f us  mfma-frac %.3f" % (sys.argv[1], d["ms_per_step"], r["kernel_us"], r["cost_stage_us"], r["frac"]))
+PY
+}
+run default A=1 &&
+run sk_lpr4 KCCOT_SK_LPR=4 &&
+run sk_lpr16 KCCOT_SK_LPR=16 &&
+run gram_wgs512 KCCOT_GRAM_WGS=512 &&
+run gram_wgs128 KCCOT_GRAM_WGS=128 &&
+run gram_wgs384 KCCOT_GRAM_WGS=384
