@@ -59,6 +59,23 @@ __device__ __forceinline__ float seg_sum(float v) {
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * LN2; }
 
+// Diagnostic build only (-DKCCOT_DIAG, libkccot_diag.so, tools/diag_sinkhorn.py): in-kernel
+// s_memtime stamps of one half-step.  The product library contains no stamp.
+#ifdef KCCOT_DIAG
+#define KCCOT_STAMP(SLOT)                                                                         \
+    do {                                                                                          \
+        if (a.diag && it == 50) {                                                                 \
+            unsigned long long tt_;                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");          \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            if ((threadIdx.x & 63) == 0) a.diag[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (SLOT)] = tt_; \
+        }                                                                                         \
+    } while (0)
+#else
+#define KCCOT_STAMP(SLOT) do {} while (0)
+#endif
+
 struct SinkArgs {
     const float* C;       // [nprob,n,n]
     int n, L, Lmin, stop_mode;
@@ -68,6 +85,7 @@ struct SinkArgs {
     float* cost_out;      // [nprob]
     int32_t* nits_out;    // [nprob]
     float* pi_out;        // [nprob,n,n] or null
+    unsigned long long* diag;   // diagnostic build only; null otherwise
 };
 
 // Load the EPT contiguous duals a thread needs (entries q*EPT .. q*EPT+EPT-1) from LDS.
@@ -150,22 +168,29 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
     int nits = 0;
     for (int it = 0; it < a.L; ++it) {
         // every lane executes the half-steps (DPP reads neighbours); only real lines store
+        KCCOT_STAMP(0);
         const float ui = u_s[lsafe];
         const float un = half_step<EPT, LPR, true>(crow, ui, v_s, q, eps, inv_eps, log_w);
+        KCCOT_STAMP(1);
         float du = 0.f;
         if (active && q == 0) {
             u_s[line] = un;
             du = fabsf(un - ui);
             if (a.u_hist) a.u_hist[((int64_t)p * a.L + it) * n + line] = un;
         }
+        KCCOT_STAMP(2);
         __syncthreads();
+        KCCOT_STAMP(3);
         const float vj = v_s[lsafe];
         const float vn = half_step<EPT, LPR, false>(ccol, vj, u_s, q, eps, inv_eps, log_w);
+        KCCOT_STAMP(4);
         if (active && q == 0) {
             v_s[line] = vn;
             if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + line] = vn;
         }
+        KCCOT_STAMP(5);
         __syncthreads();
+        KCCOT_STAMP(6);
         nits = it + 1;
         // gan_utils.py:157-160 (count-based) / :115-117 (index-based).  err is only needed once
         // the stop rule can fire, and never on the last iteration.
@@ -385,7 +410,10 @@ struct SinkGeom { int lpr, ept, threads; };
 
 static SinkGeom sink_geom(int n) {
     SinkGeom g;
-    g.lpr = (n <= 32) ? 16 : 8;                       // n*lpr <= 1024 for n <= 128
+    // n*lpr <= 1024.  Measured at n = 64 (stamped diagnostic build, tools/diag_sinkhorn.py): a
+    // half-step is a dependent chain of ~110 VALU instructions per wave, so more waves per SIMD
+    // (16 lanes per line = 1024 threads) hide more of it than fewer, longer threads.
+    g.lpr = (n <= 64) ? 16 : 8;
     if (n > 32 && n <= 64) {
         // tuning knob for the configs[1] size: 4, 8 or 16 lanes per line (256 / 512 / 1024 threads)
         const char* e = getenv("KCCOT_SK_LPR");
@@ -442,7 +470,11 @@ extern "C" int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float ep
         return fail(KCCOT_EUNSUPPORTED, "sinkhorn_fwd: n=%d > %d (the multi-CU solver for larger "
                     "batches is not built yet)", n, SK_MAXN);
     SinkGeom g = sink_geom(n);
-    SinkArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out};
+    SinkArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
+               nullptr};
+#ifdef KCCOT_DIAG
+    a.diag = static_cast<unsigned long long*>(ws);   // diagnostic build: ws carries the stamp buffer
+#endif
     hipStream_t st = (hipStream_t)stream;
     KCCOT_SK_DISPATCH(sinkhorn_fwd_reg, a, g, nprob, st)
     return launch_status("sinkhorn_fwd_reg");
