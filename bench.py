@@ -138,7 +138,7 @@ def main():
     if world > 1:
         from kccotgan_amd import dist as kd
         shard = kd.shard_batch(t, rank, world)
-        step = lambda: kd.sharded_loss_step(shard, SC, rank, world)
+        step = lambda: kd.sharded_loss_step(shard, SC)
     else:
         step = lambda: loss_step(G, t)
 

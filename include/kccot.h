@@ -90,6 +90,16 @@ int kccot_pairwise_cost3_bwd_f32(const float* g3, const float* real, const float
                                  float* dfake, float* dh_fake, float* dh_real, float* dm_real,
                                  float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream);
 
+/* Same for the batch rows [row_begin, row_begin+row_count) only (the batch-sharded caller: every
+ * rank holds the full, replicated g3 and all videos after the all-gather and needs the gradient
+ * of ITS samples; outputs are [row_count, ...]). */
+int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* real, const float* fake, int B,
+                                      int64_t K, float sc, const float* h_fake, const float* h_real,
+                                      const float* m_real, const float* m_fake, int T, int J,
+                                      int row_begin, int row_count,
+                                      float* dfake, float* dh_fake, float* dh_real, float* dm_real,
+                                      float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream);
+
 /* Backward of one general cost matrix (cost_xy / modified_cost): given g = dLoss/dC [Bx,By]
  * writes dx [Bx,K], dy [By,K], dh [Bx,T,J], dM [By,T,J]; any of them may be NULL.  With
  * KCCOT_COST_SAME (x is y) pass dy = NULL: dx receives both contributions. */

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void build_coeffs(int mode, const float* __res
 
 // out[m0+mm][k] = sum_r Wt[r][m0+mm] * Z_r[k];  one column k per thread, MB output rows per block row.
 template <int MB>
-__global__ __launch_bounds__(256) void apply_coeffs(const float* __restrict__ Wt, const float* __restrict__ src1, int n1,
+__global__ __launch_bounds__(256) void apply_coeffs(const float* __restrict__ Wt, int wpitch,
+                                                    const float* __restrict__ src1, int n1,
                                                     const float* __restrict__ src2, int n2, int Bout, int64_t K,
                                                     float* __restrict__ out) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void apply_coeffs(const float* __restrict__ Wt
         const float z = kok ? src1[(int64_t)r * K + k] : 0.f;
 #pragma unroll
         for (int mm = 0; mm < MB; ++mm) {
-            const float w = (m0 + mm < Bout) ? wrow[(int64_t)r * Bout + mm] : 0.f;
+            const float w = (m0 + mm < Bout) ? wrow[(int64_t)r * wpitch + mm] : 0.f;
             acc[mm] = fmaf(w, z, acc[mm]);
         }
     }
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void apply_coeffs(const float* __restrict__ Wt
         const float z = kok ? src2[(int64_t)r * K + k] : 0.f;
 #pragma unroll
         for (int mm = 0; mm < MB; ++mm) {
-            const float w = (m0 + mm < Bout) ? wrow[(int64_t)(n1 + r) * Bout + mm] : 0.f;
+            const float w = (m0 + mm < Bout) ? wrow[(int64_t)(n1 + r) * wpitch + mm] : 0.f;
             acc[mm] = fmaf(w, z, acc[mm]);
         }
     }
@@ -109,8 +110,9 @@ __global__ __launch_bounds__(256) void apply_coeffs(const float* __restrict__ Wt
 // loss).  One launch handles up to four outputs (blockIdx.z); block = 16 (a) x 16 (k) outputs.
 enum { CG_H = 0, CG_M = 1 };
 struct CausalGradJob {
-    float* out;          // [Ba, T*J]
-    int mode, Ba, Bb;
+    float* out;          // [Ba, T*J]: rows a_begin .. a_begin+Ba-1 of the full problem
+    int mode, Ba, Bb, a_begin;
+    int pitch;           // row pitch (= full column count Bj) of the g matrices
     const float* g[2];   // [Bi, Bj] row-major (Bi = rows of C); null = term absent
     const float* src[2]; // CG_H: M [Bb,T,J];  CG_M: h [Bb,T,J]
 };
@@ -123,8 +125,10 @@ __global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, i
     const int a0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
     if (a0 >= jb.Ba) return;   // block-uniform
     const int t = threadIdx.x, ta = t >> 4, tk = t & 15;
-    // C is [Bi,Bj]: for CG_H rows a index Bi (= Ba) and b runs over Bj (= Bb); for CG_M the reverse
-    const int Bj = (jb.mode == CG_H) ? jb.Bb : jb.Ba;
+    // g is [Bi,Bj] with row pitch jb.pitch (= Bj): for CG_H `a` indexes its rows and b its columns,
+    // for CG_M the reverse
+    const int Bj = jb.pitch;
+    const int ab = jb.a_begin;
     float tot = 0.f;
     for (int term = 0; term < 2; ++term) {
         const float* g = jb.g[term];
@@ -136,10 +140,10 @@ __global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, i
                 const int e = t + 256 * m;
                 if (jb.mode == CG_H) {
                     const int ar = e >> 6, bb = e & 63;
-                    sg[ar * 65 + bb] = (a0 + ar < jb.Ba && b0 + bb < jb.Bb) ? g[(int64_t)(a0 + ar) * Bj + b0 + bb] : 0.f;
+                    sg[ar * 65 + bb] = (a0 + ar < jb.Ba && b0 + bb < jb.Bb) ? g[(int64_t)(ab + a0 + ar) * Bj + b0 + bb] : 0.f;
                 } else {
                     const int bb = e >> 4, ar = e & 15;
-                    sg[ar * 65 + bb] = (a0 + ar < jb.Ba && b0 + bb < jb.Bb) ? g[(int64_t)(b0 + bb) * Bj + a0 + ar] : 0.f;
+                    sg[ar * 65 + bb] = (a0 + ar < jb.Ba && b0 + bb < jb.Bb) ? g[(int64_t)(b0 + bb) * Bj + ab + a0 + ar] : 0.f;
                 }
                 const int bb = e >> 4, kk = e & 15, k = k0 + kk;
                 float x = 0.f;
@@ -186,8 +190,9 @@ constexpr int AM_COLS = 64;
 constexpr int AM_ROWS = 128;
 
 template <int NSTEPS>
-__global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict__ Wt, const float* __restrict__ src1,
-                                                         int n1, const float* __restrict__ src2, int n2, int Bout,
+__global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict__ Wt, int wpitch,
+                                                         const float* __restrict__ src1, int n1,
+                                                         const float* __restrict__ src2, int n2, int Bout,
                                                          int64_t K, int64_t ntiles, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float zs[AM_ROWS * AM_COLS];
     const int t = threadIdx.x, lane = t & 63;
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
             const int r = 2 * s + (lane >> 5);
-            afrag[s] = (r < R && m < Bout) ? Wt[(int64_t)r * Bout + m] : 0.f;
+            afrag[s] = (r < R && m < Bout) ? Wt[(int64_t)r * wpitch + m] : 0.f;
         }
     }
     // staging: thread holds float4 at columns c4..c4+3 of stack rows (t>>4) + 16*j, j < 8
@@ -250,24 +255,25 @@ __global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict
 }
 
 
-static int launch_apply(const float* Wt, const float* s1, int n1, const float* s2, int n2, int Bout, int64_t K,
-                        float* out, hipStream_t st) {
+// Wt points at the first wanted output row's column; wpitch = full number of output rows of W
+static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, const float* s2, int n2, int Bout,
+                        int64_t K, float* out, hipStream_t st) {
     const bool al = (K % 4 == 0) && ((uintptr_t)s1 % 16 == 0) && (n2 == 0 || (uintptr_t)s2 % 16 == 0);
     if (al && n1 + n2 <= AM_ROWS && Bout <= 64) {
         const int64_t ntiles = (K + AM_COLS - 1) / AM_COLS;
         const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);   // 2 workgroups per CU (VGPR-limited)
         const int R = n1 + n2;
         const float* s2p = s2 ? s2 : s1;
-        if (R > 64) hipLaunchKernelGGL(apply_coeffs_mfma<64>, dim3(grid), dim3(256), 0, st, Wt, s1, n1, s2p, n2, Bout, K, ntiles, out);
-        else if (R > 32) hipLaunchKernelGGL(apply_coeffs_mfma<32>, dim3(grid), dim3(256), 0, st, Wt, s1, n1, s2p, n2, Bout, K, ntiles, out);
-        else hipLaunchKernelGGL(apply_coeffs_mfma<16>, dim3(grid), dim3(256), 0, st, Wt, s1, n1, s2p, n2, Bout, K, ntiles, out);
+        if (R > 64) hipLaunchKernelGGL(apply_coeffs_mfma<64>, dim3(grid), dim3(256), 0, st, Wt, wpitch, s1, n1, s2p, n2, Bout, K, ntiles, out);
+        else if (R > 32) hipLaunchKernelGGL(apply_coeffs_mfma<32>, dim3(grid), dim3(256), 0, st, Wt, wpitch, s1, n1, s2p, n2, Bout, K, ntiles, out);
+        else hipLaunchKernelGGL(apply_coeffs_mfma<16>, dim3(grid), dim3(256), 0, st, Wt, wpitch, s1, n1, s2p, n2, Bout, K, ntiles, out);
         return launch_status("apply_coeffs_mfma");
     }
     const unsigned gx = (unsigned)((K + 255) / 256);
-    if (Bout <= 8) hipLaunchKernelGGL(apply_coeffs<8>, dim3(gx, 1), dim3(256), 0, st, Wt, s1, n1, s2, n2, Bout, K, out);
-    else if (Bout <= 16) hipLaunchKernelGGL(apply_coeffs<16>, dim3(gx, 1), dim3(256), 0, st, Wt, s1, n1, s2, n2, Bout, K, out);
-    else if (Bout <= 32) hipLaunchKernelGGL(apply_coeffs<32>, dim3(gx, 1), dim3(256), 0, st, Wt, s1, n1, s2, n2, Bout, K, out);
-    else hipLaunchKernelGGL(apply_coeffs<64>, dim3(gx, (Bout + 63) / 64), dim3(256), 0, st, Wt, s1, n1, s2, n2, Bout, K, out);
+    if (Bout <= 8) hipLaunchKernelGGL(apply_coeffs<8>, dim3(gx, 1), dim3(256), 0, st, Wt, wpitch, s1, n1, s2, n2, Bout, K, out);
+    else if (Bout <= 16) hipLaunchKernelGGL(apply_coeffs<16>, dim3(gx, 1), dim3(256), 0, st, Wt, wpitch, s1, n1, s2, n2, Bout, K, out);
+    else if (Bout <= 32) hipLaunchKernelGGL(apply_coeffs<32>, dim3(gx, 1), dim3(256), 0, st, Wt, wpitch, s1, n1, s2, n2, Bout, K, out);
+    else hipLaunchKernelGGL(apply_coeffs<64>, dim3(gx, (Bout + 63) / 64), dim3(256), 0, st, Wt, wpitch, s1, n1, s2, n2, Bout, K, out);
     return launch_status("apply_coeffs");
 }
 
@@ -281,12 +287,15 @@ extern "C" size_t kccot_pairwise_cost3_bwd_workspace_bytes(int B, int64_t K) {
     return align_up((size_t)2 * B * B * sizeof(float), 256);
 }
 
-extern "C" int kccot_pairwise_cost3_bwd_f32(const float* g3, const float* real, const float* fake, int B,
-                                            int64_t K, float sc, const float* h_fake, const float* h_real,
-                                            const float* m_real, const float* m_fake, int T, int J,
-                                            float* dfake, float* dh_fake, float* dh_real, float* dm_real,
-                                            float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream) {
+extern "C" int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* real, const float* fake, int B,
+                                                 int64_t K, float sc, const float* h_fake, const float* h_real,
+                                                 const float* m_real, const float* m_fake, int T, int J,
+                                                 int row_begin, int row_count,
+                                                 float* dfake, float* dh_fake, float* dh_real, float* dm_real,
+                                                 float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream) {
     if (!g3 || !real || !fake) return fail(KCCOT_EINVAL, "pairwise_cost3_bwd: null pointer");
+    if (row_begin < 0 || row_count <= 0 || row_begin + row_count > B)
+        return fail(KCCOT_EINVAL, "pairwise_cost3_bwd: bad row range [%d, %d) of %d", row_begin, row_begin + row_count, B);
     if (B <= 0 || K <= 0 || T < 1 || J < 1)
         return fail(KCCOT_EINVAL, "pairwise_cost3_bwd: bad shape B=%d K=%lld T=%d J=%d", B, (long long)K, T, J);
     if ((dh_fake || dh_real || dm_real || dm_fake) && (!h_fake || !h_real || !m_real || !m_fake))
@@ -303,16 +312,25 @@ extern "C" int kccot_pairwise_cost3_bwd_f32(const float* g3, const float* real, 
         hipLaunchKernelGGL(build_coeffs, dim3(B), dim3(256), 0, st, (int)CO_LOSS3_DFAKE,
                            gxy, gyy, B, B, sc, Wt);
         if ((rc = launch_status("build_coeffs"))) return rc;
-        if ((rc = launch_apply(Wt, real, B, fake, B, B, K, dfake, st))) return rc;
+        if ((rc = launch_apply(Wt + row_begin, B, real, B, fake, B, row_count, K, dfake, st))) return rc;
     }
     // gan_utils.py:221-223: h_fake rows of xy (cols m_real) and of yy (cols m_fake); h_real rows of xx
     // (cols m_real); m_real cols of xy (rows h_fake) and of xx (rows h_real); m_fake cols of yy (rows h_fake)
     CausalGradBatch cg{};
-    if (dh_fake) cg.job[cg.njobs++] = CausalGradJob{dh_fake, CG_H, B, B, {gxy, gyy}, {m_real, m_fake}};
-    if (dh_real) cg.job[cg.njobs++] = CausalGradJob{dh_real, CG_H, B, B, {gxx, nullptr}, {m_real, nullptr}};
-    if (dm_real) cg.job[cg.njobs++] = CausalGradJob{dm_real, CG_M, B, B, {gxy, gxx}, {h_fake, h_real}};
-    if (dm_fake) cg.job[cg.njobs++] = CausalGradJob{dm_fake, CG_M, B, B, {gyy, nullptr}, {h_fake, nullptr}};
+    if (dh_fake) cg.job[cg.njobs++] = CausalGradJob{dh_fake, CG_H, row_count, B, row_begin, B, {gxy, gyy}, {m_real, m_fake}};
+    if (dh_real) cg.job[cg.njobs++] = CausalGradJob{dh_real, CG_H, row_count, B, row_begin, B, {gxx, nullptr}, {m_real, nullptr}};
+    if (dm_real) cg.job[cg.njobs++] = CausalGradJob{dm_real, CG_M, row_count, B, row_begin, B, {gxy, gxx}, {h_fake, h_real}};
+    if (dm_fake) cg.job[cg.njobs++] = CausalGradJob{dm_fake, CG_M, row_count, B, row_begin, B, {gyy, nullptr}, {h_fake, nullptr}};
     return launch_causal_grads(cg, T, J, sc, st);
+}
+
+extern "C" int kccot_pairwise_cost3_bwd_f32(const float* g3, const float* real, const float* fake, int B,
+                                            int64_t K, float sc, const float* h_fake, const float* h_real,
+                                            const float* m_real, const float* m_fake, int T, int J,
+                                            float* dfake, float* dh_fake, float* dh_real, float* dm_real,
+                                            float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream) {
+    return kccot_pairwise_cost3_bwd_rows_f32(g3, real, fake, B, K, sc, h_fake, h_real, m_real, m_fake, T, J, 0, B,
+                                             dfake, dh_fake, dh_real, dm_real, dm_fake, ws, ws_bytes, stream);
 }
 
 extern "C" size_t kccot_pairwise_cost_bwd_workspace_bytes(int Bx, int By) {
@@ -347,24 +365,24 @@ extern "C" int kccot_pairwise_cost_bwd_f32(const float* g, const float* x, const
             hipLaunchKernelGGL(build_coeffs, dim3(Bx), dim3(256), 0, st, (int)CO_SAME, g,
                                (const float*)nullptr, Bx, Bx, sc, W1);
             if ((rc = launch_status("build_coeffs"))) return rc;
-            if ((rc = launch_apply(W1, x, Bx, x, 0, Bx, K, dx, st))) return rc;
+            if ((rc = launch_apply(W1, Bx, x, Bx, x, 0, Bx, K, dx, st))) return rc;
         }
     } else {
         if (dx) {
             hipLaunchKernelGGL(build_coeffs, dim3(Bx), dim3(256), 0, st, (int)CO_DX, g,
                                (const float*)nullptr, Bx, By, sc, W1);
             if ((rc = launch_status("build_coeffs"))) return rc;
-            if ((rc = launch_apply(W1, x, Bx, y, By, Bx, K, dx, st))) return rc;
+            if ((rc = launch_apply(W1, Bx, x, Bx, y, By, Bx, K, dx, st))) return rc;
         }
         if (dy) {
             hipLaunchKernelGGL(build_coeffs, dim3(By), dim3(256), 0, st, (int)CO_DY, g,
                                (const float*)nullptr, Bx, By, sc, W2);
             if ((rc = launch_status("build_coeffs"))) return rc;
-            if ((rc = launch_apply(W2, x, Bx, y, By, By, K, dy, st))) return rc;
+            if ((rc = launch_apply(W2, By, x, Bx, y, By, By, K, dy, st))) return rc;
         }
     }
     CausalGradBatch cg{};
-    if (dh) cg.job[cg.njobs++] = CausalGradJob{dh, CG_H, Bx, By, {g, nullptr}, {M, nullptr}};
-    if (dM) cg.job[cg.njobs++] = CausalGradJob{dM, CG_M, By, Bx, {g, nullptr}, {h, nullptr}};
+    if (dh) cg.job[cg.njobs++] = CausalGradJob{dh, CG_H, Bx, By, 0, By, {g, nullptr}, {M, nullptr}};
+    if (dM) cg.job[cg.njobs++] = CausalGradJob{dM, CG_M, By, Bx, 0, By, {g, nullptr}, {h, nullptr}};
     return launch_causal_grads(cg, T, J, sc, st);
 }

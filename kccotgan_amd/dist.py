@@ -1,0 +1,165 @@
+"""Batch-sharded evaluation of compute_sinkhorn_loss over the GPUs of one node (one process per
+GPU, torch.distributed over RCCL/xGMI).  The reference has no distributed code at all
+(SURVEY.md section 5); this is the new design of SURVEY.md section 8(e):
+
+  1. every rank owns B/G samples of real / fake and of the four feature tensors;
+  2. ALL-GATHER the video shards and the (KB-sized) features -> every rank holds [B,K] of both;
+  3. rank g builds the ROW BLOCKS C_xy[I_g,:], C_xx[I_g,:], C_yy[I_g,:] ([B/G, B] each);
+  4. ALL-GATHER the row blocks (3*B*B*4 bytes in total) -> the full cost matrices, replicated;
+  5. every rank runs the identical (deterministic) Sinkhorn forward and reverse sweep: the loss
+     and dLoss/dC are bitwise the same everywhere, no communication;
+  6. rank g forms the gradients of ITS samples from the replicated dLoss/dC and the gathered
+     videos (kccot_pairwise_cost3_bwd_rows_f32): NO reduce-scatter of video-sized gradients.
+
+The returned loss is the GLOBAL-batch loss (identical on every rank).  Parameter gradients that
+flow back through a rank's local samples are therefore partial sums: combine them with an
+all-reduce SUM (not the mean DistributedDataParallel applies by default).
+
+The arithmetic is done by the HIP library (``HipOps``).  ``ops`` is injectable so that the
+sharding / collective logic can be exercised over gloo on a CPU-only box by the tests (which plug
+in the CPU oracle there); the product never does.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_of, workspace
+
+_THRESH = 10 ** (-2)
+_LMIN = 100
+
+
+class HipOps:
+    """The four device operations of the sharded path, through the C-ABI."""
+
+    @staticmethod
+    def cost_rows(x_rows, y_full, h_rows, M_full, sc):
+        Bx, K = x_rows.shape
+        By = y_full.shape[0]
+        T, J = h_rows.shape[1], h_rows.shape[2]
+        C = torch.empty((Bx, By), dtype=torch.float32, device=x_rows.device)
+        ws, wsb = workspace(lib.kccot_pairwise_cost_workspace_bytes(Bx, By, K), x_rows)
+        check(lib.kccot_pairwise_cost_f32(ptr(x_rows), ptr(y_full), Bx, By, K, sc, ptr(h_rows), ptr(M_full), None, None,
+                                          T, J, 0, ptr(C), ws, wsb, stream_of(x_rows)), "pairwise_cost")
+        return C
+
+    @staticmethod
+    def sinkhorn3_fwd(C3, eps, L):
+        nprob, n, _ = C3.shape
+        dev = C3.device
+        Lh = max(int(L), 1)
+        u_hist = torch.empty((nprob, Lh, n), dtype=torch.float32, device=dev)
+        v_hist = torch.empty((nprob, Lh, n), dtype=torch.float32, device=dev)
+        cost = torch.empty((nprob,), dtype=torch.float32, device=dev)
+        nits = torch.empty((nprob,), dtype=torch.int32, device=dev)
+        check(lib.kccot_sinkhorn_fwd_f32(ptr(C3), nprob, n, float(eps), int(L), _LMIN, _THRESH, _lib.STOP_COUNT,
+                                         ptr(u_hist), ptr(v_hist), ptr(cost), ptr(nits), None, None, 0,
+                                         stream_of(C3)), "sinkhorn_fwd")
+        return cost, (C3, u_hist, v_hist, nits, float(eps), Lh)
+
+    @staticmethod
+    def sinkhorn3_bwd(saved, gcost3):
+        C3, u_hist, v_hist, nits, eps, Lh = saved
+        nprob, n, _ = C3.shape
+        dC3 = torch.empty_like(C3)
+        check(lib.kccot_sinkhorn_bwd_f32(ptr(C3), ptr(u_hist), ptr(v_hist), ptr(nits), nprob, n, eps, Lh,
+                                         ptr(gcost3.contiguous()), ptr(dC3), None, 0, stream_of(C3)), "sinkhorn_bwd")
+        return dC3
+
+    @staticmethod
+    def cost3_bwd_rows(dC3, real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, row_count):
+        B, K = real.shape
+        T, J = h_fake.shape[1], h_fake.shape[2]
+        dev = real.device
+        dfake = torch.empty((row_count, K), dtype=torch.float32, device=dev)
+        dhf, dhr, dmr, dmf = (torch.empty((row_count, T, J), dtype=torch.float32, device=dev) for _ in range(4))
+        ws, wsb = workspace(lib.kccot_pairwise_cost3_bwd_workspace_bytes(B, K), real)
+        check(lib.kccot_pairwise_cost3_bwd_rows_f32(ptr(dC3), ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real),
+                                                    ptr(m_real), ptr(m_fake), T, J, row_begin, row_count, ptr(dfake),
+                                                    ptr(dhf), ptr(dhr), ptr(dmr), ptr(dmf), ws, wsb, stream_of(real)),
+              "pairwise_cost3_bwd_rows")
+        return dfake, dhf, dhr, dmr, dmf
+
+
+def all_gather_cat(t, group=None):
+    """Concatenate the ranks' equally shaped tensors along dim 0.  RCCL handles device tensors
+    directly; the gloo backend (CPU rehearsal) is staged through host memory."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return t
+    t = t.contiguous()
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
+        dist.all_gather(parts, t.cpu(), group=group)
+        return torch.cat(parts, 0).to(t.device)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
+class _ShardedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, real_l, fake_l, h_fake_l, h_real_l, m_real_l, m_fake_l, sc, eps, L, group, ops):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        Bl = real_l.shape[0]
+        real = all_gather_cat(real_l, group)
+        fake = all_gather_cat(fake_l, group)
+        # the four [Bl,T,J] feature shards travel as one message
+        feats = all_gather_cat(torch.stack([h_fake_l, h_real_l, m_real_l, m_fake_l], dim=1), group)
+        h_fake, h_real, m_real, m_fake = (feats[:, i].contiguous() for i in range(4))
+        # row blocks of the three cost matrices (gan_utils.py:221-223)
+        blk = torch.stack([ops.cost_rows(real_l, fake, h_fake_l, m_real, sc),
+                           ops.cost_rows(real_l, real, h_real_l, m_real, sc),
+                           ops.cost_rows(fake_l, fake, h_fake_l, m_fake, sc)], dim=0)            # [3,Bl,B]
+        C3 = all_gather_cat(blk.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()  # [3,B,B]
+        cost3, saved = ops.sinkhorn3_fwd(C3, eps, L)
+        ctx.saved_state = (saved, real, fake, h_fake, h_real, m_real, m_fake)
+        ctx.cfg = (sc, rank * Bl, Bl, ops)
+        ctx.nits = saved[3] if isinstance(saved, tuple) and len(saved) > 3 else None
+        return (2.0 * cost3[0] - cost3[1]) - cost3[2]           # gan_utils.py:225
+
+    @staticmethod
+    def backward(ctx, g):
+        saved, real, fake, h_fake, h_real, m_real, m_fake = ctx.saved_state
+        sc, row_begin, Bl, ops = ctx.cfg
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("the loss path never differentiates w.r.t. real (kernel_train.py:252,289)")
+        g = g.reshape(())
+        gcost3 = torch.stack([2.0 * g, -g, -g])                 # d(2 xy - xx - yy)
+        dC3 = ops.sinkhorn3_bwd(saved, gcost3)
+        dfake, dhf, dhr, dmr, dmf = ops.cost3_bwd_rows(dC3, real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, Bl)
+        return None, dfake, dhf, dhr, dmr, dmf, None, None, None, None, None
+
+
+def sharded_sinkhorn_loss(f_real_l, f_fake_l, scaling_coef, h_fake_l, m_real_l, h_real_l, m_fake_l, group=None,
+                          ops=None, epsilon=1.0, L=100):
+    """compute_sinkhorn_loss (gan_utils.py:204-227) of the GLOBAL batch from per-rank shards.
+    Arguments are this rank's [B/G, ...] slices, in the reference's order h_fake, m_real, h_real,
+    m_fake.  epsilon / L default to what the reference effectively runs (1.0, 100)."""
+    ops = ops or HipOps
+    Bl = f_real_l.shape[0]
+    cast = (lambda v: v.float()) if ops is HipOps else (lambda v: v)   # the HIP kernels are fp32
+    flat = lambda v: cast(v.reshape(Bl, -1)).contiguous()
+    feat = lambda v: cast(v).contiguous()
+    return _ShardedLoss.apply(flat(f_real_l), flat(f_fake_l), feat(h_fake_l), feat(h_real_l), feat(m_real_l),
+                              feat(m_fake_l), float(scaling_coef), float(epsilon), int(L), group, ops).reshape(())
+
+
+# ---- helpers used by bench.py ---------------------------------------------------------------------
+def shard_batch(t, rank, world):
+    """Slice the leading (batch) axis of every tensor of a dict into this rank's shard."""
+    out = {}
+    for k, v in t.items():
+        B = v.shape[0]
+        if B % world:
+            raise ValueError("batch %d is not divisible by %d ranks" % (B, world))
+        s = v.detach()[rank * (B // world):(rank + 1) * (B // world)].contiguous()
+        out[k] = s.requires_grad_(k != "real")
+    return out
+
+
+def sharded_loss_step(shard, sc, group=None):
+    loss = sharded_sinkhorn_loss(shard["real"], shard["fake"], sc, shard["h_fake"], shard["m_real"], shard["h_real"],
+                                 shard["m_fake"], group)
+    grads = torch.autograd.grad(loss, [shard[k] for k in ("fake", "h_fake", "h_real", "m_real", "m_fake")])
+    return loss, grads

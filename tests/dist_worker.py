@@ -1,0 +1,75 @@
+"""Worker + test-only ops for the batch-sharded path (spawned by tests/test_dist_*.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import cases  # noqa: E402
+from oracle import gan_utils_torch as ot  # noqa: E402
+
+
+class OracleOps:
+    """CPU stand-in for the four device operations, built on the torch oracle (fp64 autograd).
+    TEST ONLY: lets the gloo tests exercise gather / row-block / index logic without a GPU."""
+
+    @staticmethod
+    def _cost(x, y, h, M, sc):
+        return ot.cost_xy(x.unsqueeze(1), y.unsqueeze(1), sc) + ot.causal_term(h, M, sc)
+
+    @staticmethod
+    def cost_rows(x_rows, y_full, h_rows, M_full, sc):
+        return OracleOps._cost(x_rows, y_full, h_rows, M_full, sc)
+
+    @staticmethod
+    def sinkhorn3_fwd(C3, eps, L):
+        with torch.enable_grad():
+            leaf = C3.detach().clone().requires_grad_(True)
+            costs = torch.stack([ot.sinkhorn_from_cost(leaf[p], eps, L)[0] for p in range(3)])
+        return costs.detach(), (leaf, costs)
+
+    @staticmethod
+    def sinkhorn3_bwd(saved, gcost3):
+        leaf, costs = saved
+        return torch.autograd.grad(costs, leaf, gcost3.to(costs.dtype))[0]
+
+    @staticmethod
+    def cost3_bwd_rows(dC3, real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, row_count):
+        with torch.enable_grad():
+            v = [t.detach().clone().requires_grad_(True) for t in (fake, h_fake, h_real, m_real, m_fake)]
+            f, hf, hr, mr, mf = v
+            C3 = torch.stack([OracleOps._cost(real, f, hf, mr, sc), OracleOps._cost(real, real, hr, mr, sc),
+                              OracleOps._cost(f, f, hf, mf, sc)])
+            grads = torch.autograd.grad(C3, v, dC3)
+        return tuple(g[row_begin:row_begin + row_count].contiguous() for g in grads)
+
+
+def run(rank, world, port, shape, seed, regime, device, use_hip, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kccotgan_amd import dist as kd
+    inp = cases.gen_inputs(shape, seed, regime)
+    dtype = torch.float32 if use_hip else torch.float64
+    t = {k: torch.from_numpy(v).to(dtype).to(device) for k, v in inp.items()}
+    shard = kd.shard_batch(t, rank, world)
+    loss = kd.sharded_sinkhorn_loss(shard["real"], shard["fake"], cases.SC, shard["h_fake"], shard["m_real"],
+                                    shard["h_real"], shard["m_fake"], ops=None if use_hip else OracleOps)
+    names = ("fake", "h_fake", "h_real", "m_real", "m_fake")
+    grads = torch.autograd.grad(loss, [shard[k] for k in names])
+    res = {"loss": np.array(float(loss))}
+    for k, g in zip(names, grads):
+        res["d" + k] = g.detach().cpu().double().numpy()
+    np.savez(out_path % rank, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    a = sys.argv
+    run(int(a[1]), int(a[2]), int(a[3]), a[4], int(a[5]), a[6], a[7], a[8] == "hip", a[9])

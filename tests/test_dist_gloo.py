@@ -1,0 +1,86 @@
+"""The batch-sharded path (kccotgan_amd/dist.py) over gloo with world_size 2.
+
+CPU: the sharding / all-gather / row-block assembly / local-gradient logic with the oracle
+plugged in as the compute ops (no GPU here) against the single-process oracle.
+GPU (-m gpu): the same with the real HIP ops -- two ranks sharing cuda:0 over gloo -- against the
+single-process HIP result (sharded == 1-GPU to <= 1e-6 relative)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import gan_utils_torch as ot
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NAMES = ("fake", "h_fake", "h_real", "m_real", "m_fake")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(world, shape, seed, regime, device, mode, tmp_path):
+    port = free_port()
+    out = os.path.join(str(tmp_path), "rank%d.npz")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port),
+                               shape, str(seed), regime, device, mode, out]) for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [np.load(out % r) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("shape,seed,regime", [("small", 1, "far"), ("small", 0, "near")])
+def test_sharded_equals_single_process_oracle(world, shape, seed, regime, tmp_path):
+    res = launch(world, shape, seed, regime, "cpu", "oracle", tmp_path)
+    inp = cases.gen_inputs(shape, seed, regime)
+    t = {k: torch.from_numpy(v).double() for k, v in inp.items()}
+    for k in NAMES:
+        t[k].requires_grad_(True)
+    ref = ot.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"],
+                                   t["m_fake"])
+    grads = torch.autograd.grad(ref, [t[k] for k in NAMES])
+    B = inp["real"].shape[0]
+    Bl = B // world
+    for r, out in enumerate(res):
+        assert abs(float(out["loss"]) - float(ref)) <= 1e-10 * abs(float(ref))       # replicated global loss
+        for k, g in zip(NAMES, grads):
+            want = g.numpy().reshape(B, -1)[r * Bl:(r + 1) * Bl]
+            got = out["d" + k].reshape(Bl, -1)
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * max(np.abs(g.numpy()).max(), 1e-30), err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,seed,regime", [("deci64", 0, "near"), ("cfg1", 1, "far")])
+def test_sharded_hip_equals_single_gpu(shape, seed, regime, tmp_path):
+    from kccotgan_amd import gan_utils as G
+    res = launch(2, shape, seed, regime, "cuda:0", "hip", tmp_path)
+    inp = cases.gen_inputs(shape, seed, regime)
+    t = {k: torch.from_numpy(v).to("cuda:0") for k, v in inp.items()}
+    for k in NAMES:
+        t[k].requires_grad_(True)
+    ref = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"],
+                                  t["m_fake"])
+    grads = torch.autograd.grad(ref, [t[k] for k in NAMES])
+    B = inp["real"].shape[0]
+    Bl = B // 2
+    for r, out in enumerate(res):
+        assert abs(float(out["loss"]) - float(ref)) <= 1e-6 * abs(float(ref))
+        for k, g in zip(NAMES, grads):
+            g = g.cpu().double().numpy()
+            want = g.reshape(B, -1)[r * Bl:(r + 1) * Bl]
+            np.testing.assert_allclose(out["d" + k].reshape(Bl, -1), want, rtol=0, atol=2e-5 * np.abs(g).max(), err_msg=k)
