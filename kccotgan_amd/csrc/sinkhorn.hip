@@ -428,11 +428,21 @@ static SinkGeom sink_geom(int n) {
 
 }  // namespace kccot
 
+namespace kccot {
+// sinkhorn_gen.hip: streaming kernels for 128 < n <= 1024
+size_t sinkhorn_gen_workspace_bytes(int nprob, int n);
+int launch_sinkhorn_fwd_gen(const float* C, int nprob, int n, float eps, int L, int Lmin, float thresh, int stop_mode,
+                            float* u_hist, float* v_hist, float* cost_out, int32_t* nits_out, float* pi_out, void* ws,
+                            size_t ws_bytes, hipStream_t st);
+int launch_sinkhorn_bwd_gen(const float* C, const float* u_hist, const float* v_hist, const int32_t* nits, int nprob, int n,
+                            float eps, int L, const float* gcost, float* dC, void* ws, size_t ws_bytes, hipStream_t st);
+}  // namespace kccot
+
 using namespace kccot;
 
 extern "C" size_t kccot_sinkhorn_workspace_bytes(int nprob, int n) {
-    (void)nprob; (void)n;
-    return 0;   // the register-resident kernels need none; kept for the large-n path
+    if (nprob <= 0 || n <= SK_MAXN) return 0;   // the register-resident kernels need none
+    return sinkhorn_gen_workspace_bytes(nprob, n);
 }
 
 #define KCCOT_SK_LAUNCH(KERNEL, E, P, ARGS, GEOM, NPROB, ST) \
@@ -458,7 +468,6 @@ extern "C" int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float ep
                                       float thresh, int stop_mode, float* u_hist, float* v_hist,
                                       float* cost_out, int32_t* nits_out, float* pi_out, void* ws,
                                       size_t ws_bytes, kccot_stream_t stream) {
-    (void)ws; (void)ws_bytes;
     if (!C || !cost_out || !nits_out) return fail(KCCOT_EINVAL, "sinkhorn_fwd: null pointer");
     if (nprob <= 0 || n <= 0 || L < 0 || !(eps > 0.f))
         return fail(KCCOT_EINVAL, "sinkhorn_fwd: bad arguments nprob=%d n=%d L=%d eps=%g", nprob, n, L, (double)eps);
@@ -467,8 +476,8 @@ extern "C" int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float ep
     if (stop_mode != KCCOT_STOP_COUNT && stop_mode != KCCOT_STOP_INDEX)
         return fail(KCCOT_EINVAL, "sinkhorn_fwd: bad stop_mode %d", stop_mode);
     if (n > SK_MAXN)
-        return fail(KCCOT_EUNSUPPORTED, "sinkhorn_fwd: n=%d > %d (the multi-CU solver for larger "
-                    "batches is not built yet)", n, SK_MAXN);
+        return launch_sinkhorn_fwd_gen(C, nprob, n, eps, L, Lmin, thresh, stop_mode, u_hist, v_hist, cost_out, nits_out,
+                                       pi_out, ws, ws_bytes, (hipStream_t)stream);
     SinkGeom g = sink_geom(n);
     SinkArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
                nullptr};
@@ -484,13 +493,13 @@ extern "C" int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const
                                       const int32_t* nits, int nprob, int n, float eps, int L,
                                       const float* gcost, float* dC_out, void* ws, size_t ws_bytes,
                                       kccot_stream_t stream) {
-    (void)ws; (void)ws_bytes;
     if (!C || !u_hist || !v_hist || !nits || !gcost || !dC_out)
         return fail(KCCOT_EINVAL, "sinkhorn_bwd: null pointer");
     if (nprob <= 0 || n <= 0 || L < 0 || !(eps > 0.f))
         return fail(KCCOT_EINVAL, "sinkhorn_bwd: bad arguments nprob=%d n=%d L=%d eps=%g", nprob, n, L, (double)eps);
     if (n > SK_MAXN)
-        return fail(KCCOT_EUNSUPPORTED, "sinkhorn_bwd: n=%d > %d", n, SK_MAXN);
+        return launch_sinkhorn_bwd_gen(C, u_hist, v_hist, nits, nprob, n, eps, L, gcost, dC_out, ws, ws_bytes,
+                                       (hipStream_t)stream);
     SinkGeom g = sink_geom(n);
     SinkBwdArgs a{C, u_hist, v_hist, nits, gcost, dC_out, n, L, eps, (float)(1.0 / (double)eps)};
     hipStream_t st = (hipStream_t)stream;

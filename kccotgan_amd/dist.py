@@ -52,8 +52,9 @@ class HipOps:
         v_hist = torch.empty((nprob, Lh, n), dtype=torch.float32, device=dev)
         cost = torch.empty((nprob,), dtype=torch.float32, device=dev)
         nits = torch.empty((nprob,), dtype=torch.int32, device=dev)
+        ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(nprob, n), C3)
         check(lib.kccot_sinkhorn_fwd_f32(ptr(C3), nprob, n, float(eps), int(L), _LMIN, _THRESH, _lib.STOP_COUNT,
-                                         ptr(u_hist), ptr(v_hist), ptr(cost), ptr(nits), None, None, 0,
+                                         ptr(u_hist), ptr(v_hist), ptr(cost), ptr(nits), None, ws, wsb,
                                          stream_of(C3)), "sinkhorn_fwd")
         return cost, (C3, u_hist, v_hist, nits, float(eps), Lh)
 
@@ -62,8 +63,9 @@ class HipOps:
         C3, u_hist, v_hist, nits, eps, Lh = saved
         nprob, n, _ = C3.shape
         dC3 = torch.empty_like(C3)
+        ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(nprob, n), C3)
         check(lib.kccot_sinkhorn_bwd_f32(ptr(C3), ptr(u_hist), ptr(v_hist), ptr(nits), nprob, n, eps, Lh,
-                                         ptr(gcost3.contiguous()), ptr(dC3), None, 0, stream_of(C3)), "sinkhorn_bwd")
+                                         ptr(gcost3.contiguous()), ptr(dC3), ws, wsb, stream_of(C3)), "sinkhorn_bwd")
         return dC3
 
     @staticmethod

@@ -170,8 +170,9 @@ class _Sinkhorn(torch.autograd.Function):
         v_hist = torch.empty((nprob, Lh, n), dtype=torch.float32, device=dev) if keep else None
         cost = torch.empty((nprob,), dtype=torch.float32, device=dev)
         nits = torch.empty((nprob,), dtype=torch.int32, device=dev)
+        ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(nprob, n), C)
         check(lib.kccot_sinkhorn_fwd_f32(ptr(C), nprob, n, float(eps), int(L), int(Lmin), _THRESH, stop_mode,
-                                         ptr(u_hist), ptr(v_hist), ptr(cost), ptr(nits), None, None, 0,
+                                         ptr(u_hist), ptr(v_hist), ptr(cost), ptr(nits), None, ws, wsb,
                                          stream_of(C)), "sinkhorn_fwd")
         last_info[tag] = nits
         if keep:
@@ -185,8 +186,9 @@ class _Sinkhorn(torch.autograd.Function):
         nprob, n, _ = C.shape
         gcost = gcost.contiguous().float()
         dC = torch.empty_like(C)
+        ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(nprob, n), C)
         check(lib.kccot_sinkhorn_bwd_f32(ptr(C), ptr(u_hist), ptr(v_hist), ptr(nits), nprob, n, ctx.eps, ctx.Lh,
-                                         ptr(gcost), ptr(dC), None, 0, stream_of(C)), "sinkhorn_bwd")
+                                         ptr(gcost), ptr(dC), ws, wsb, stream_of(C)), "sinkhorn_bwd")
         return dC, None, None, None, None, None
 
 

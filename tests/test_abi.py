@@ -42,6 +42,8 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.kccot_sinkhorn_fwd_f32(one, 1, 0, 1.0, 10, 10, 0.01, 0, None, None, one, one, None, None, 0, None) == _lib.EINVAL
     assert lib.kccot_sinkhorn_fwd_f32(one, 1, 8, -1.0, 10, 10, 0.01, 0, None, None, one, one, None, None, 0, None) == _lib.EINVAL
     assert lib.kccot_sinkhorn_fwd_f32(one, 1, 4096, 1.0, 10, 10, 0.01, 0, None, None, one, one, None, None, 0, None) == _lib.EUNSUPPORTED
+    assert lib.kccot_sinkhorn_fwd_f32(one, 1, 512, 1.0, 10, 10, 0.01, 0, None, None, one, one, None, None, 0, None) == _lib.EWORKSPACE
+    assert lib.kccot_sinkhorn_workspace_bytes(3, 64) == 0 and lib.kccot_sinkhorn_workspace_bytes(3, 512) >= 2 * 3 * 512 * 512 * 4
     assert lib.kccot_smooth_fwd_f32(one, 2, 8, 3, 8, 1, 5.0, 3, _lib.SMOOTH_T, one, one, one, 1 << 30, None) == _lib.EINVAL  # radius >= T
     assert lib.kccot_martingale_fwd_f32(one, 0, 4, 4, 1.0, 1.0, one, None) == _lib.EINVAL
 

@@ -194,6 +194,52 @@ def test_sinkhorn_kats(G, L):
             assert rel(got[p], o.sinkhorn_from_cost(Cn[p], 0.5, 37)[0]) < 2e-5, (n, p)
 
 
+def test_sinkhorn_large_n_streaming_path(G, L):
+    """n > 128 (BASELINE configs 3-5 batch sizes): the streaming kernels, forward and reverse sweep,
+    against the oracle / fp64 autograd on random cost matrices."""
+    for n, Lc, eps in ((130, 25, 0.7), (256, 40, 1.0), (512, 12, 0.5)):
+        Cn = (np.random.default_rng(n).random((2, n, n), dtype=np.float32) * 6).astype(np.float32)
+        C = torch.from_numpy(Cn).to(DEV).requires_grad_(True)
+        cost = G._Sinkhorn.apply(C, eps, Lc, 100, L.STOP_COUNT, "large")
+        w = torch.tensor([1.0, -0.5], device=DEV)
+        (cost * w).sum().backward()
+        assert G.last_info["large"].tolist() == [Lc, Lc]
+        for p in range(2):
+            Cd = torch.from_numpy(Cn[p]).double().requires_grad_(True)
+            ref, nits = ot.sinkhorn_from_cost(Cd, eps, Lc)
+            ref.backward()
+            assert rel(cost[p], ref) < 2e-5, (n, p)
+            gref = Cd.grad.numpy() * float(w[p])
+            np.testing.assert_allclose(C.grad[p].cpu().numpy(), gref, rtol=0, atol=2e-4 * np.abs(gref).max())
+
+
+@pytest.mark.parametrize("B", [128, 256])
+def test_loss_at_larger_batches(G, B):
+    """configs 3/4 batch sizes (decimated frames so that the CPU oracle finishes in seconds): direct
+    cost kernel over several 64-row tiles + Sinkhorn at n = 128 (registers) / 256 (streaming)."""
+    rng = np.random.default_rng(B)
+    H, T, W, Cc, J = 8, 10, 8, 3, 8
+    real = rng.random((B, H, T, W, Cc), dtype=np.float32)
+    fake = np.clip(real + np.float32(0.05) * rng.standard_normal(real.shape, dtype=np.float32), 0, 1).astype(np.float32)
+    f = {k: rng.random((B, T, J), dtype=np.float32) for k in ("h_fake", "m_real", "h_real", "m_fake")}
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in dict(real=real, fake=fake, **f).items()}
+    wrt = ["fake", "h_fake", "m_real"]
+    for k in wrt:
+        t[k].requires_grad_(True)
+    loss = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"],
+                                   t["m_fake"])
+    grads = torch.autograd.grad(loss, [t[k] for k in wrt])
+    d = {k: torch.from_numpy(v).double() for k, v in dict(real=real, fake=fake, **f).items()}
+    for k in wrt:
+        d[k].requires_grad_(True)
+    ref = ot.compute_sinkhorn_loss(d["real"], d["fake"], cases.SC, 0.8, 100, d["h_fake"], d["m_real"], d["h_real"],
+                                   d["m_fake"])
+    gref = torch.autograd.grad(ref, [d[k] for k in wrt])
+    assert rel(loss, ref) < 1e-4
+    for k, a, b in zip(wrt, grads, gref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=2e-3 * float(b.abs().max()), err_msg=k)
+
+
 # ---------------------------------------------------------------- the loss
 @pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("shape,seed,regime", ALL)
