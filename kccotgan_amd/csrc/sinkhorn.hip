@@ -14,10 +14,8 @@
 // to register, no LDS crossbar); the duals u and v are exchanged through 2*n floats of LDS
 // (ds_read_b128: a thread's EPT entries are contiguous) with ONE barrier per half-step.
 //
-// Arithmetic follows the reference's order: M = ((-C + u) + v) * (1/eps);
-// lse = log(sum(exp(M - max))) + max; u = eps*(log(1/n) - lse) + u, then v with the new u.
-// exp/log are the hardware v_exp_f32 / v_log_f32 (base 2, 1 ulp): arguments are <= 0 after the
-// max shift, so the relative error of the sum stays at the 1e-7 level.
+// The iteration is the reference's (max-shifted LSE over ((-C + u) + v)/eps, u then v with the new
+// u), carried in log2 units so that exp/log are the hardware v_exp_f32 / v_log_f32 (see half_step).
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -103,46 +101,70 @@ __device__ __forceinline__ void load_other(float (&o)[EPT], const float* arr, in
     }
 }
 
-// One half-step for the calling thread's line: returns the updated dual value of the line.
-// Entries past the matrix edge carry c = +inf and become exp(-inf) = 0.
+// ---- log2-domain half-step ---------------------------------------------------------------------
+// With k2 = log2(e)/eps the kernels carry  c2 = C*k2,  U = u*k2,  V = v*k2  and evaluate
+//     y = (U_i - c2_ij) + V_j            [= ((-C+u)+v)/eps * log2(e), same association as gan_utils.py:153]
+//     lse2 = log2(sum_j exp2(y - max)) + max,      U_i <- (log2(1/n) - lse2) + U_i
+// which is the reference's update  u <- eps*(log(1/n) - LSE) + u  multiplied through by k2: two
+// adds per entry instead of add/add/mul/mul, exp2/log2 are single hardware instructions, and the
+// two-wide vector type lets hipcc issue packed v_pk_add_f32.  The iterates are the same numbers in
+// other units; only fp32 rounding differs (the duals are O(1e3) with an ulp of 1e-4 either way).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int EPT, int LPR, bool ROW>
-__device__ __forceinline__ float half_step(const float (&c)[EPT], float self, const float* other, int q,
-                                           float eps, float inv_eps, float log_w) {
-    float o[EPT], x[EPT];
+__device__ __forceinline__ float half_step(const float (&c2)[EPT], float self, const float* other, int q, float lw2) {
+    float o[EPT];
     load_other<EPT>(o, other, q);
-    float mx = -INFINITY;
+    float y[EPT];
+    if constexpr (EPT >= 2) {
 #pragma unroll
-    for (int m = 0; m < EPT; ++m) {
-        // gan_utils.py:153,155: (-C + u + v^T)/eps evaluates as ((-C + u) + v)/eps
-        const float t = ROW ? ((-c[m] + self) + o[m]) : ((-c[m] + o[m]) + self);
-        x[m] = t * inv_eps;
-        mx = fmaxf(mx, x[m]);
+        for (int m = 0; m < EPT; m += 2) {
+            f32x2 cc = {c2[m], c2[m + 1]}, oo = {o[m], o[m + 1]}, ss = {self, self};
+            const f32x2 t = ROW ? ((ss - cc) + oo) : ((oo - cc) + ss);
+            y[m] = t.x; y[m + 1] = t.y;
+        }
+    } else {
+        y[0] = ROW ? ((self - c2[0]) + o[0]) : ((o[0] - c2[0]) + self);
     }
+    float mx = y[0];
+#pragma unroll
+    for (int m = 1; m < EPT; ++m) mx = fmaxf(mx, y[m]);
     mx = seg_max<LPR>(mx);
     // tf.reduce_logsumexp: a non-finite max is replaced by 0
     const float shift = (mx > -INFINITY && mx < INFINITY) ? mx : 0.f;
     float e[EPT];
+    if constexpr (EPT >= 2) {
+        const f32x2 sh = {shift, shift};
 #pragma unroll
-    for (int m = 0; m < EPT; ++m) e[m] = __builtin_amdgcn_exp2f((x[m] - shift) * LOG2E);
+        for (int m = 0; m < EPT; m += 2) {
+            const f32x2 yy = {y[m], y[m + 1]};
+            const f32x2 d = yy - sh;
+            e[m] = __builtin_amdgcn_exp2f(d.x);
+            e[m + 1] = __builtin_amdgcn_exp2f(d.y);
+        }
+    } else {
+        e[0] = __builtin_amdgcn_exp2f(y[0] - shift);
+    }
     // pairwise tree: log2(EPT) dependent adds instead of EPT
 #pragma unroll
     for (int w = 1; w < EPT; w *= 2)
 #pragma unroll
         for (int m = 0; m + w < EPT; m += 2 * w) e[m] += e[m + w];
     const float s = seg_sum<LPR>(e[0]);
-    const float lse = fast_log(s) + shift;
-    return eps * (log_w - lse) + self;   // gan_utils.py:154,156
+    const float lse2 = __builtin_amdgcn_logf(s) + shift;
+    return (lw2 - lse2) + self;   // gan_utils.py:154,156 in log2 units
 }
 
+// c2 = C * k2 in both orientations; entries past the matrix edge are +inf (-> exp2(-inf) = 0)
 template <int EPT, int LPR>
-__device__ __forceinline__ void load_costs(const float* __restrict__ C, int n, int line, int q, float (&crow)[EPT],
-                                           float (&ccol)[EPT]) {
+__device__ __forceinline__ void load_costs(const float* __restrict__ C, int n, int line, int q, float k2,
+                                           float (&crow)[EPT], float (&ccol)[EPT]) {
 #pragma unroll
     for (int m = 0; m < EPT; ++m) {
         const int idx = q * EPT + m;
         const bool ok = line < n && idx < n;
-        crow[m] = ok ? C[(int64_t)line * n + idx] : INFINITY;
-        ccol[m] = ok ? C[(int64_t)idx * n + line] : INFINITY;
+        crow[m] = ok ? C[(int64_t)line * n + idx] * k2 : INFINITY;
+        ccol[m] = ok ? C[(int64_t)idx * n + line] * k2 : INFINITY;
     }
 }
 
@@ -156,34 +178,35 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
     const int t = threadIdx.x, line = t / LPR, q = t % LPR;
     const bool active = line < n;
     const float* C = a.C + (int64_t)p * n * n;
-    const float eps = a.eps, inv_eps = a.inv_eps;
+    const float k2 = a.inv_eps * LOG2E;
 
     float crow[EPT], ccol[EPT];
-    load_costs<EPT, LPR>(C, n, line, q, crow, ccol);
+    load_costs<EPT, LPR>(C, n, line, q, k2, crow, ccol);
     for (int i = t; i < SK_MAXN + 16 * 16; i += blockDim.x) { u_s[i] = 0.f; v_s[i] = 0.f; }   // gan_utils.py:147
     __syncthreads();
 
-    const float log_w = logf(1.0f / (float)n);     // log(mu) = log(nu), gan_utils.py:138-139
-    const int lsafe = active ? line : 0;
+    const float lw2 = __builtin_amdgcn_logf(1.0f / (float)n);   // log2(mu) = log2(nu), gan_utils.py:138-139
+    // stop rule in log2 units: sum|u-u_prev| = sum|U-U_prev| * eps*ln2
+    const float err_scale = a.eps * LN2;
     int nits = 0;
+    float ui = 0.f, vj = 0.f;   // this line's duals (every lane of the line holds them)
     for (int it = 0; it < a.L; ++it) {
         // every lane executes the half-steps (DPP reads neighbours); only real lines store
         KCCOT_STAMP(0);
-        const float ui = u_s[lsafe];
-        const float un = half_step<EPT, LPR, true>(crow, ui, v_s, q, eps, inv_eps, log_w);
+        const float un = half_step<EPT, LPR, true>(crow, ui, v_s, q, lw2);
         KCCOT_STAMP(1);
-        float du = 0.f;
+        const float du = (active && q == 0) ? fabsf(un - ui) : 0.f;
+        ui = un;
         if (active && q == 0) {
             u_s[line] = un;
-            du = fabsf(un - ui);
             if (a.u_hist) a.u_hist[((int64_t)p * a.L + it) * n + line] = un;
         }
         KCCOT_STAMP(2);
         __syncthreads();
         KCCOT_STAMP(3);
-        const float vj = v_s[lsafe];
-        const float vn = half_step<EPT, LPR, false>(ccol, vj, u_s, q, eps, inv_eps, log_w);
+        const float vn = half_step<EPT, LPR, false>(ccol, vj, u_s, q, lw2);
         KCCOT_STAMP(4);
+        vj = vn;
         if (active && q == 0) {
             v_s[line] = vn;
             if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + line] = vn;
@@ -196,21 +219,20 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
         // the stop rule can fire, and never on the last iteration.
         const bool reached = (a.stop_mode == KCCOT_STOP_INDEX) ? (it >= a.Lmin) : (nits >= a.Lmin);
         if (reached && it + 1 < a.L) {
-            const float err = block_sum(du, red);
+            const float err = block_sum(du, red) * err_scale;
             if (a.thresh > err) break;
         }
     }
 
-    // gan_utils.py:162-164: pi = exp((-C + u + v^T)/eps); cost = sum(pi * C)
+    // gan_utils.py:162-164: pi = exp((-C + u + v^T)/eps); cost = sum(pi * C)   (C re-read: L2-resident)
     float part = 0.f;
     if (active) {
-        const float ui = u_s[line];
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
             const int idx = q * EPT + m;
             if (idx < n) {
-                const float pi = fast_exp(((-crow[m] + ui) + v_s[idx]) * inv_eps);
-                part += pi * crow[m];
+                const float pi = __builtin_amdgcn_exp2f((ui - crow[m]) + v_s[idx]);
+                part += pi * C[(int64_t)line * n + idx];
                 if (a.pi_out) a.pi_out[(int64_t)p * n * n + (int64_t)line * n + idx] = pi;
             }
         }
@@ -230,9 +252,10 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
 //   du_t/dv_{t-1} = -P_t,  du_t/dC = +P_t,  du_t/du_{t-1} = 1 - sum_j P_t = 0
 //   dv_t/du_t     = -Q_t,  dv_t/dC = +Q_t,  dv_t/dv_{t-1} = 1 - sum_i Q_t = 0
 // and, from the update rules themselves, no reduction has to be redone:
-//   Q_t[i,j] = exp((-C_ij + u_t,i + v_t,j     - a)/eps)
-//   P_t[i,j] = exp((-C_ij + u_t,i + v_{t-1,j} - a)/eps)
+//   Q_t[i,j] = exp((-C_ij + u_t,i + v_t,j     - a)/eps) = exp2((U_t,i - c2_ij) + V_t,j     - log2(1/n))
+//   P_t[i,j] = exp((-C_ij + u_t,i + v_{t-1,j} - a)/eps) = exp2((U_t,i - c2_ij) + V_{t-1,j} - log2(1/n))
 // (the two "= 0" terms are 1e-7-sized rounding residues in the reference's tape; dropped).
+// The history holds the duals in the forward's log2 units (U, V); gradients are in natural units.
 //
 // Per iteration, newest first:   (A) row pass with Q_t:    gu_i -= sum_j Q_ij gv_j ; dC += Q_ij gv_j
 //                                (B) column pass with P_t: gv_j = -sum_i P_ij gu_i ; dC += P_ij gu_i
@@ -263,13 +286,13 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
     const int t = threadIdx.x, line = t / LPR, q = t % LPR;
     const bool active = line < n;
     const float* C = a.C + (int64_t)p * n * n;
-    const float eps = a.eps, inv_eps = a.inv_eps, g = a.gcost[p];
+    const float k2 = a.inv_eps * LOG2E, g = a.gcost[p];
     const int nits = a.nits[p];
     const float* uh = a.u_hist + (int64_t)p * a.L * n;
     const float* vh = a.v_hist + (int64_t)p * a.L * n;
 
     float crow[EPT], ccol[EPT], drow[EPT], dcol[EPT];
-    load_costs<EPT, LPR>(C, n, line, q, crow, ccol);
+    load_costs<EPT, LPR>(C, n, line, q, k2, crow, ccol);
 #pragma unroll
     for (int m = 0; m < EPT; ++m) { drow[m] = 0.f; dcol[m] = 0.f; }
     for (int i = t; i < PADN; i += blockDim.x) {
@@ -277,8 +300,8 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
         gu[i] = gv[i] = 0.f;
     }
     __syncthreads();
-    // history index k holds (u_{k+1}, v_{k+1}); iteration `it` (1-based) lives in slot it & 1;
-    // v_0 = 0
+    // history index k holds (U_{k+1}, V_{k+1}); iteration `it` (1-based) lives in slot it & 1;
+    // V_0 = 0
     auto hist_u = [&](int it, int i) { return it >= 1 ? uh[(int64_t)(it - 1) * n + i] : 0.f; };
     auto hist_v = [&](int it, int i) { return it >= 1 ? vh[(int64_t)(it - 1) * n + i] : 0.f; };
     if (t < n) {
@@ -286,17 +309,17 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
         V[nits & 1][t] = hist_v(nits, t);
         V[(nits - 1) & 1][t] = hist_v(nits - 1, t);
     }
-    // prefetch for the first in-loop refill: u_{nits-1}, v_{nits-2}
+    // prefetch for the first in-loop refill: U_{nits-1}, V_{nits-2}
     float nu = (t < n) ? hist_u(nits - 1, t) : 0.f;
     float nv = (t < n) ? hist_v(nits - 2, t) : 0.f;
     __syncthreads();
 
-    // cost = sum_ij pi_ij C_ij, pi = exp((-C+u+v)/eps):
+    const int lsafe = active ? line : 0;
+    // cost = sum_ij pi_ij C_ij, pi = exp2((U - c2) + V);  C/eps = c2*ln2:
     //   dcost/dC_ij (direct) = pi_ij (1 - C_ij/eps); dcost/du_i = sum_j pi_ij C_ij/eps; same for v
     {
         const float* Uc = U[nits & 1];
         const float* Vc = V[nits & 1];
-        const int lsafe = active ? line : 0;
         const float ui = Uc[lsafe], vj = Vc[lsafe];
         float ov[EPT], ou[EPT];
         load_other<EPT>(ov, Vc, q);
@@ -306,36 +329,34 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
         for (int m = 0; m < EPT; ++m) {
             const bool ok = active && (q * EPT + m) < n;
             const float cr = ok ? crow[m] : 0.f, cc = ok ? ccol[m] : 0.f;
-            const float pr = ok ? fast_exp(((-cr + ui) + ov[m]) * inv_eps) : 0.f;
-            drow[m] = g * pr * (1.f - cr * inv_eps);
+            const float pr = ok ? __builtin_amdgcn_exp2f((ui - cr) + ov[m]) : 0.f;
+            drow[m] = g * pr * (1.f - cr * LN2);
             su += pr * cr;
-            const float pc = ok ? fast_exp(((-cc + ou[m]) + vj) * inv_eps) : 0.f;
+            const float pc = ok ? __builtin_amdgcn_exp2f((ou[m] - cc) + vj) : 0.f;
             sv += pc * cc;
         }
         su = seg_sum<LPR>(su);
         sv = seg_sum<LPR>(sv);
-        if (active && q == 0) { gu[line] = g * su * inv_eps; gv[line] = g * sv * inv_eps; }
+        if (active && q == 0) { gu[line] = g * su * LN2; gv[line] = g * sv * LN2; }
     }
-    const float aconst = eps * logf(1.0f / (float)n);
+    const float lw2 = __builtin_amdgcn_logf(1.0f / (float)n);
     __syncthreads();
 
     for (int it = nits; it >= 1; --it) {
         const float* Uc = U[it & 1];
         const float* Vc = V[it & 1];
         const float* Vp = V[(it - 1) & 1];
-        const int lsafe = active ? line : 0;
         // (A) through v_t: row pass with Q_t
         {
-            const float ui = Uc[lsafe];
+            const float ui = Uc[lsafe] - lw2;
             float ov[EPT], og[EPT];
             load_other<EPT>(ov, Vc, q);
             load_other<EPT>(og, gv, q);
             float s = 0.f;
 #pragma unroll
             for (int m = 0; m < EPT; ++m) {
-                // entries past the edge: c = +inf -> exp2(-inf) = 0
-                const float qq = fast_exp((((-crow[m] + ui) + ov[m]) - aconst) * inv_eps);
-                const float w = qq * og[m];
+                // entries past the edge: c2 = +inf -> exp2(-inf) = 0
+                const float w = __builtin_amdgcn_exp2f((ui - crow[m]) + ov[m]) * og[m];
                 drow[m] += w;
                 s += w;
             }
@@ -344,8 +365,8 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
             if (active && q == 0) gu[line] = (it == nits ? gu[line] : 0.f) - s;
         }
         __syncthreads();
-        // refill the slots the older iteration needs: U[(it-1)&1] <- u_{it-1}, V[it&1] <- v_{it-2}
-        // (v_t is dead after pass A; u_{it-1}'s slot was last read in iteration it+1)
+        // refill the slots the older iteration needs: U[(it-1)&1] <- U_{it-1}, V[it&1] <- V_{it-2}
+        // (V_t is dead after pass A; U_{it-1}'s slot was last read in iteration it+1)
         if (t < n) {
             U[(it - 1) & 1][t] = nu;
             V[it & 1][t] = nv;
@@ -354,15 +375,14 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
         }
         // (B) through u_t: column pass with P_t
         {
-            const float vj = Vp[lsafe];
+            const float vj = Vp[lsafe] - lw2;
             float ou[EPT], og[EPT];
             load_other<EPT>(ou, Uc, q);
             load_other<EPT>(og, gu, q);
             float r = 0.f;
 #pragma unroll
             for (int m = 0; m < EPT; ++m) {
-                const float pp = fast_exp((((-ccol[m] + ou[m]) + vj) - aconst) * inv_eps);
-                const float w = pp * og[m];
+                const float w = __builtin_amdgcn_exp2f((ou[m] - ccol[m]) + vj) * og[m];
                 dcol[m] += w;
                 r += w;
             }

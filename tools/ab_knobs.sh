@@ -5,7 +5,7 @@ OUT=gpurun_out/${1:-ab}
 mkdir -p "$OUT"
 run() {
     local tag=$1; shift
-    env "$@" timeout -k 10 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/$tag.json" 2> "$OUT/$tag.err" || { echo "$tag failed"; tail -5 "$OUT/$tag.err"; return 1; }
+    env "$@" timeout -k 10 300 python bench.py --steps 200 --warmup 30 --no-cpu-baseline > "$OUT/$tag.json" 2> "$OUT/$tag.err" || { echo "$tag failed"; tail -5 "$OUT/$tag.err"; return 1; }
     python - "$tag" "$OUT/$tag.json" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
@@ -13,9 +13,9 @@ r=d["roofline"]
 print("%-22s ms/step %.4f  cost-kernel %.1f us  cost-stage %.1f us  mfma-frac %.3f" % (sys.argv[1], d["ms_per_step"], r["kernel_us"], r["cost_stage_us"], r["frac"]))
 PY
 }
-run default A=1 &&
-run sk_lpr4 KCCOT_SK_LPR=4 &&
-run sk_lpr16 KCCOT_SK_LPR=16 &&
-run gram_wgs512 KCCOT_GRAM_WGS=512 &&
-run gram_wgs128 KCCOT_GRAM_WGS=128 &&
-run gram_wgs384 KCCOT_GRAM_WGS=384
+for rep in 1 2; do
+run default_$rep A=1 &&
+run sk_lpr4_$rep KCCOT_SK_LPR=4 &&
+run sk_lpr8_$rep KCCOT_SK_LPR=8 &&
+run sk_lpr16_$rep KCCOT_SK_LPR=16 || exit 1
+done
