@@ -128,6 +128,211 @@ __global__ __launch_bounds__(256) void maxnorm_bwd_apply(const float* __restrict
     ds[e] = v;
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused plane kernel: T-, W- and H-convolution in ONE pass over the tensor.
+//
+// A workgroup owns one sample b and a segment of HSEG image rows h.  It streams the (T x W*C)
+// planes of that segment (7.7 KB at 30 x 64 x 1) through LDS: the T- and W-stencils run inside the
+// plane (no halo: both axes lie fully inside it), and the H-stencil is a sliding window of the
+// last 2R+1 planes kept in registers (each thread owns PPT fixed positions of the plane), so every
+// input element is read once per segment (+R halo planes either side, served by L2) and every
+// output element is written once, coalesced.  The global maximum costs no extra pass over HBM
+// either: pass 1 runs the same kernel WITHOUT writing (block maxima only), pass 2 recomputes and
+// writes s / max -- the 31 MB input is still in the 256 MB Infinity Cache.
+//
+// The same kernel is the backward (ADJ): the adjoint of "REFLECT-pad then correlate" along an axis
+// of length L is again a gather over the +-R window, with position-dependent weights
+//     din[p] = sum_{|k|<=R, 0<=p+k<L} g[p+k] * ( w[k] + [p>=1] wq(-2p-k) + [p<=L-2] wq(2(L-1)-2p-k) )
+// (wq = w inside +-R, 0 outside), and the load stage forms ds = gout/m - [out==1]*corr on the fly.
+// ------------------------------------------------------------------------------------------
+constexpr int SP_PPT = 8;
+
+struct PlaneArgs {
+    const float* in;       // forward: input video; adjoint: gout
+    const float* out_fwd;  // adjoint only: the forward's normalised output (arg-max detection)
+    float* out;            // forward pass 2: normalised output; adjoint: din; null in pass 1
+    float* blockmax;       // forward pass 1: per-workgroup maxima
+    const float* mx;       // device scalar: tensor maximum (pass 2 / adjoint)
+    const float* res;      // adjoint: {sum gout*out, #ties}
+    int B, H, T, W, C, hseg;
+    unsigned axes;
+    Taps tp;
+};
+
+template <int R>
+__device__ __forceinline__ float wq(const Taps& tp, int d) { return (d >= -R && d <= R) ? tp.w[d + R] : 0.f; }
+
+// weight of source position p+k for output position p (axis length L); returns false if the
+// source does not exist (adjoint) -- forward always returns true with src = reflect(p+k)
+template <int R, bool ADJ>
+__device__ __forceinline__ bool tap(const Taps& tp, int p, int k, int L, int& src, float& w) {
+    if (!ADJ) { src = reflect(p + k, L); w = tp.w[k + R]; return true; }
+    src = p + k;
+    if (src < 0 || src >= L) return false;
+    w = tp.w[k + R] + (p >= 1 ? wq<R>(tp, -2 * p - k) : 0.f) + (p <= L - 2 ? wq<R>(tp, 2 * (L - 1) - 2 * p - k) : 0.f);
+    return true;
+}
+
+template <int R, bool ADJ>
+__global__ __launch_bounds__(1024) void smooth_plane(PlaneArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sp_lds[];
+    __shared__ float red[16];
+    const int T = a.T, WC = a.W * a.C, P = T * WC;       // plane size
+    float* bufA = sp_lds;
+    float* bufB = sp_lds + P;
+    const int b = blockIdx.y, h0 = blockIdx.x * a.hseg;
+    const int h1 = min(h0 + a.hseg, a.H);
+    const bool doT = a.axes & KCCOT_SMOOTH_T, doH = a.axes & KCCOT_SMOOTH_H, doW = a.axes & KCCOT_SMOOTH_W;
+    const int nth = blockDim.x, t = threadIdx.x;
+    const int64_t plane_stride = (int64_t)P, sample_stride = (int64_t)a.H * P;
+    const float* inb = a.in + (int64_t)b * sample_stride;
+    const float* ofb = ADJ ? a.out_fwd + (int64_t)b * sample_stride : nullptr;
+    float* outb = a.out ? a.out + (int64_t)b * sample_stride : nullptr;
+    float m = 1.f, corr = 0.f;
+    if (ADJ) { m = a.mx[0]; corr = a.res[1] > 0.f ? a.res[0] / (m * a.res[1]) : 0.f; }
+    else if (outb) m = a.mx[0];
+
+    // positions owned by this thread: pos = t + nth*i  (consecutive threads, consecutive addresses)
+    int prow[SP_PPT], pcol[SP_PPT], pw[SP_PPT];   // t index, w*C+c index, w index
+    bool pok[SP_PPT];
+#pragma unroll
+    for (int i = 0; i < SP_PPT; ++i) {
+        const int pos = t + nth * i;
+        pok[i] = pos < P;
+        prow[i] = pok[i] ? pos / WC : 0;
+        pcol[i] = pok[i] ? pos % WC : 0;
+        pw[i] = pcol[i] / a.C;
+    }
+    float win[SP_PPT][2 * R + 1];
+#pragma unroll
+    for (int i = 0; i < SP_PPT; ++i)
+#pragma unroll
+        for (int j = 0; j <= 2 * R; ++j) win[i][j] = 0.f;
+
+    float vmax = -FLT_MAX;
+    const int hlo = doH ? h0 - R : h0, hhi = doH ? h1 + R : h1;   // planes to stream
+    for (int hp = hlo; hp < hhi; ++hp) {
+        // ---- load plane hp (forward: reflected index; adjoint: zero plane outside [0,H))
+        int hsrc = hp;
+        bool exists = true;
+        if (!ADJ) hsrc = reflect(hp, a.H); else exists = hp >= 0 && hp < a.H;
+        float v[SP_PPT];
+#pragma unroll
+        for (int i = 0; i < SP_PPT; ++i) {
+            v[i] = 0.f;
+            if (pok[i] && exists) {
+                const int64_t off = (int64_t)hsrc * plane_stride + t + nth * i;
+                if (!ADJ) v[i] = inb[off];
+                else { const float o = ofb[off]; v[i] = inb[off] / m - (o == 1.0f ? corr : 0.f); }
+            }
+        }
+        // ---- T stencil inside the plane
+        if (doT) {
+            __syncthreads();   // previous plane's readers of bufA are done
+#pragma unroll
+            for (int i = 0; i < SP_PPT; ++i) if (pok[i]) bufA[t + nth * i] = v[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SP_PPT; ++i) {
+                float acc = 0.f;
+                if (pok[i]) {
+#pragma unroll
+                    for (int k = -R; k <= R; ++k) {
+                        int src; float w;
+                        if (tap<R, ADJ>(a.tp, prow[i], k, T, src, w)) acc = fmaf(w, bufA[src * WC + pcol[i]], acc);
+                    }
+                }
+                v[i] = acc;
+            }
+        }
+        // ---- W stencil inside the plane (stride C along the contiguous W*C axis)
+        if (doW) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SP_PPT; ++i) if (pok[i]) bufB[t + nth * i] = v[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SP_PPT; ++i) {
+                float acc = 0.f;
+                if (pok[i]) {
+                    const int wpos = pw[i], c = pcol[i] - wpos * a.C;
+                    const float* rowp = bufB + prow[i] * WC + c;
+#pragma unroll
+                    for (int k = -R; k <= R; ++k) {
+                        int src; float w;
+                        if (tap<R, ADJ>(a.tp, wpos, k, a.W, src, w)) acc = fmaf(w, rowp[src * a.C], acc);
+                    }
+                }
+                v[i] = acc;
+            }
+        }
+        // ---- H stencil: sliding register window over planes
+        int hout = hp;   // output plane completed by this input plane
+        if (doH) {
+#pragma unroll
+            for (int i = 0; i < SP_PPT; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2 * R; ++j) win[i][j] = win[i][j + 1];
+                win[i][2 * R] = v[i];
+            }
+            hout = hp - R;
+            if (hout < h0) continue;   // window not full yet (uniform across the block)
+            float wt[2 * R + 1];
+            bool wok[2 * R + 1];
+#pragma unroll
+            for (int j = 0; j <= 2 * R; ++j) {
+                int src;
+                wok[j] = tap<R, ADJ>(a.tp, hout, j - R, a.H, src, wt[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < SP_PPT; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j <= 2 * R; ++j)
+                    if (wok[j]) acc = fmaf(wt[j], win[i][j], acc);
+                v[i] = acc;
+            }
+        }
+        // ---- emit plane hout
+#pragma unroll
+        for (int i = 0; i < SP_PPT; ++i) {
+            if (!pok[i]) continue;
+            if (!ADJ) vmax = fmaxf(vmax, v[i]);
+            if (outb) outb[(int64_t)hout * plane_stride + t + nth * i] = ADJ ? v[i] : v[i] / m;
+        }
+    }
+    if (!ADJ && a.blockmax) {
+        const float bm = block_max(vmax, red);
+        if (t == 0) a.blockmax[blockIdx.y * gridDim.x + blockIdx.x] = bm;
+    }
+}
+
+static bool plane_eligible(int T, int W, int C, int radius, int naxes) {
+    return naxes > 0 && (radius == 3 || radius == 4) && (int64_t)T * W * C <= 8192;
+}
+
+static int plane_hseg(int B, int H, bool halo) {
+    // >= 2 workgroups per CU; with an H stencil each segment re-reads 2R halo planes, so segments
+    // stay as long as that allows
+    for (int hs = halo ? 16 : 8; hs > 2; hs >>= 1)
+        if ((int64_t)B * ((H + hs - 1) / hs) >= 512) return hs;
+    return 2;
+}
+
+static int launch_plane(const PlaneArgs& pa, int radius, bool adjoint, dim3 grid, hipStream_t st) {
+    const int P = pa.T * pa.W * pa.C;
+    const int threads = ((P + SP_PPT - 1) / SP_PPT + 63) / 64 * 64;
+    const size_t lds = (size_t)2 * P * sizeof(float);
+    if (radius == 3) {
+        if (adjoint) hipLaunchKernelGGL((smooth_plane<3, true>), grid, dim3(threads), lds, st, pa);
+        else hipLaunchKernelGGL((smooth_plane<3, false>), grid, dim3(threads), lds, st, pa);
+    } else {
+        if (adjoint) hipLaunchKernelGGL((smooth_plane<4, true>), grid, dim3(threads), lds, st, pa);
+        else hipLaunchKernelGGL((smooth_plane<4, false>), grid, dim3(threads), lds, st, pa);
+    }
+    return launch_status("smooth_plane");
+}
+
 struct Axis { int len; int64_t stride; };
 
 static int collect_axes(int H, int T, int W, int C, unsigned flags, Axis* ax) {
@@ -184,6 +389,20 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
     if (ext && nodiv) return fail(KCCOT_EINVAL, "smooth_fwd: EXTERNAL_MAX and NO_DIVIDE are exclusive");
     if (na > 0 && in == out) return fail(KCCOT_EINVAL, "smooth_fwd: in-place convolution is not supported");
     const Taps tp = make_taps(sigma, radius);
+    if (plane_eligible(T, W, C, radius, na) && !nodiv) {
+        PlaneArgs pa{};
+        pa.in = in; pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C; pa.axes = flags; pa.tp = tp;
+        pa.hseg = plane_hseg(B, H, (flags & KCCOT_SMOOTH_H) != 0);
+        const dim3 grid((H + pa.hseg - 1) / pa.hseg, B);
+        if (!ext) {   // pass 1: maxima only
+            pa.out = nullptr; pa.blockmax = bmax;
+            if ((rc = launch_plane(pa, radius, false, grid, st))) return rc;
+            hipLaunchKernelGGL(reduce_blockmax, dim3(1), dim3(1024), 0, st, (const float*)bmax, (int64_t)grid.x * grid.y, max_inout);
+            if ((rc = launch_status("reduce_blockmax"))) return rc;
+        }
+        pa.out = out; pa.blockmax = nullptr; pa.mx = max_inout;   // pass 2: recompute, write s / max
+        return launch_plane(pa, radius, false, grid, st);
+    }
     const float* src = in;
     for (int i = 0; i < na; ++i) {
         float* dst = ((na - 1 - i) % 2 == 0) ? out : tmp;
@@ -234,6 +453,13 @@ extern "C" int kccot_smooth_bwd_f32(const float* gout, const float* out, const f
     if ((rc = launch_status("maxnorm_bwd_partial"))) return rc;
     hipLaunchKernelGGL(maxnorm_bwd_combine, dim3(1), dim3(1024), 0, st, (const float*)pdot, (const float*)pcnt, nb, res);
     if ((rc = launch_status("maxnorm_bwd_combine"))) return rc;
+    if (plane_eligible(T, W, C, radius, na)) {   // fused adjoint: ds formed at load time
+        PlaneArgs pa{};
+        pa.in = gout; pa.out_fwd = out; pa.out = din; pa.mx = max_in; pa.res = res;
+        pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C; pa.axes = flags; pa.tp = tp;
+        pa.hseg = plane_hseg(B, H, (flags & KCCOT_SMOOTH_H) != 0);
+        return launch_plane(pa, radius, true, dim3((H + pa.hseg - 1) / pa.hseg, B), st);
+    }
     hipLaunchKernelGGL(maxnorm_bwd_apply, dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, max_in, (const float*)res, ds);
     if ((rc = launch_status("maxnorm_bwd_apply"))) return rc;
     const float* src = ds;
