@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void maxnorm_bwd_apply(const float* __restrict
 //     din[p] = sum_{|k|<=R, 0<=p+k<L} g[p+k] * ( w[k] + [p>=1] wq(-2p-k) + [p<=L-2] wq(2(L-1)-2p-k) )
 // (wq = w inside +-R, 0 outside), and the load stage forms ds = gout/m - [out==1]*corr on the fly.
 // ------------------------------------------------------------------------------------------
-constexpr int SP_PPT = 8;
+constexpr int SP_PPT = 4;
 
 struct PlaneArgs {
     const float* in;       // forward: input video; adjoint: gout
@@ -173,8 +173,8 @@ __device__ __forceinline__ bool tap(const Taps& tp, int p, int k, int L, int& sr
     return true;
 }
 
-template <int R, bool ADJ>
-__global__ __launch_bounds__(1024) void smooth_plane(PlaneArgs a) {
+template <int R, bool ADJ, int NT>
+__global__ __launch_bounds__(NT) void smooth_plane(PlaneArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sp_lds[];
     __shared__ float red[16];
     const int T = a.T, WC = a.W * a.C, P = T * WC;       // plane size
@@ -193,15 +193,18 @@ __global__ __launch_bounds__(1024) void smooth_plane(PlaneArgs a) {
     else if (outb) m = a.mx[0];
 
     // positions owned by this thread: pos = t + nth*i  (consecutive threads, consecutive addresses)
-    int prow[SP_PPT], pcol[SP_PPT], pw[SP_PPT];   // t index, w*C+c index, w index
-    bool pok[SP_PPT];
+    int prow[SP_PPT], pcol[SP_PPT];   // t index, w*C+c index
+    bool pok[SP_PPT], tin[SP_PPT], win_[SP_PPT];
 #pragma unroll
     for (int i = 0; i < SP_PPT; ++i) {
         const int pos = t + nth * i;
         pok[i] = pos < P;
         prow[i] = pok[i] ? pos / WC : 0;
         pcol[i] = pok[i] ? pos % WC : 0;
-        pw[i] = pcol[i] / a.C;
+        const int pwi = pcol[i] / a.C;
+        // interior positions: no reflected / folded tap, the stencil is 2R+1 fixed-offset reads
+        tin[i] = prow[i] > R && prow[i] < T - 1 - R;
+        win_[i] = pwi > R && pwi < a.W - 1 - R;
     }
     float win[SP_PPT][2 * R + 1];
 #pragma unroll
@@ -236,10 +239,16 @@ __global__ __launch_bounds__(1024) void smooth_plane(PlaneArgs a) {
             for (int i = 0; i < SP_PPT; ++i) {
                 float acc = 0.f;
                 if (pok[i]) {
+                    if (tin[i]) {
+                        const float* c0 = bufA + t + nth * i;
 #pragma unroll
-                    for (int k = -R; k <= R; ++k) {
-                        int src; float w;
-                        if (tap<R, ADJ>(a.tp, prow[i], k, T, src, w)) acc = fmaf(w, bufA[src * WC + pcol[i]], acc);
+                        for (int k = -R; k <= R; ++k) acc = fmaf(a.tp.w[k + R], c0[k * WC], acc);
+                    } else {
+#pragma unroll 1
+                        for (int k = -R; k <= R; ++k) {
+                            int src; float w;
+                            if (tap<R, ADJ>(a.tp, prow[i], k, T, src, w)) acc = fmaf(w, bufA[src * WC + pcol[i]], acc);
+                        }
                     }
                 }
                 v[i] = acc;
@@ -255,12 +264,18 @@ __global__ __launch_bounds__(1024) void smooth_plane(PlaneArgs a) {
             for (int i = 0; i < SP_PPT; ++i) {
                 float acc = 0.f;
                 if (pok[i]) {
-                    const int wpos = pw[i], c = pcol[i] - wpos * a.C;
-                    const float* rowp = bufB + prow[i] * WC + c;
+                    if (win_[i]) {
+                        const float* c0 = bufB + t + nth * i;
 #pragma unroll
-                    for (int k = -R; k <= R; ++k) {
-                        int src; float w;
-                        if (tap<R, ADJ>(a.tp, wpos, k, a.W, src, w)) acc = fmaf(w, rowp[src * a.C], acc);
+                        for (int k = -R; k <= R; ++k) acc = fmaf(a.tp.w[k + R], c0[k * a.C], acc);
+                    } else {
+                        const int wpos = pcol[i] / a.C, c = pcol[i] - wpos * a.C;
+                        const float* rowp = bufB + prow[i] * WC + c;
+#pragma unroll 1
+                        for (int k = -R; k <= R; ++k) {
+                            int src; float w;
+                            if (tap<R, ADJ>(a.tp, wpos, k, a.W, src, w)) acc = fmaf(w, rowp[src * a.C], acc);
+                        }
                     }
                 }
                 v[i] = acc;
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(1024) void smooth_plane(PlaneArgs a) {
 }
 
 static bool plane_eligible(int T, int W, int C, int radius, int naxes) {
-    return naxes > 0 && (radius == 3 || radius == 4) && (int64_t)T * W * C <= 8192;
+    return naxes > 0 && (radius == 3 || radius == 4) && (int64_t)T * W * C <= 4096;
 }
 
 static int plane_hseg(int B, int H, bool halo) {
@@ -323,13 +338,14 @@ static int launch_plane(const PlaneArgs& pa, int radius, bool adjoint, dim3 grid
     const int P = pa.T * pa.W * pa.C;
     const int threads = ((P + SP_PPT - 1) / SP_PPT + 63) / 64 * 64;
     const size_t lds = (size_t)2 * P * sizeof(float);
-    if (radius == 3) {
-        if (adjoint) hipLaunchKernelGGL((smooth_plane<3, true>), grid, dim3(threads), lds, st, pa);
-        else hipLaunchKernelGGL((smooth_plane<3, false>), grid, dim3(threads), lds, st, pa);
-    } else {
-        if (adjoint) hipLaunchKernelGGL((smooth_plane<4, true>), grid, dim3(threads), lds, st, pa);
-        else hipLaunchKernelGGL((smooth_plane<4, false>), grid, dim3(threads), lds, st, pa);
-    }
+#define KCCOT_SP(RR, AA)                                                                                   \
+    do {                                                                                                   \
+        if (threads <= 512) hipLaunchKernelGGL((smooth_plane<RR, AA, 512>), grid, dim3(threads), lds, st, pa);   \
+        else hipLaunchKernelGGL((smooth_plane<RR, AA, 1024>), grid, dim3(threads), lds, st, pa);           \
+    } while (0)
+    if (radius == 3) { if (adjoint) KCCOT_SP(3, true); else KCCOT_SP(3, false); }
+    else { if (adjoint) KCCOT_SP(4, true); else KCCOT_SP(4, false); }
+#undef KCCOT_SP
     return launch_status("smooth_plane");
 }
 
