@@ -147,6 +147,13 @@ __global__ __launch_bounds__(256) void maxnorm_bwd_apply(const float* __restrict
 // ------------------------------------------------------------------------------------------
 constexpr int SP_PPT = 4;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter when stores are outstanding, which would serialise every plane behind its own output
+// store and the prefetch of the next plane; LDS visibility needs lgkmcnt(0) + s_barrier only.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct PlaneArgs {
     const float* in;       // forward: input video; adjoint: gout
     const float* out_fwd;  // adjoint only: the forward's normalised output (arg-max detection)
@@ -214,27 +221,34 @@ __global__ __launch_bounds__(NT) void smooth_plane(PlaneArgs a) {
 
     float vmax = -FLT_MAX;
     const int hlo = doH ? h0 - R : h0, hhi = doH ? h1 + R : h1;   // planes to stream
-    for (int hp = hlo; hp < hhi; ++hp) {
-        // ---- load plane hp (forward: reflected index; adjoint: zero plane outside [0,H))
+    // plane hp (forward: reflected index; adjoint: zero plane outside [0,H)), fetched one plane ahead
+    float nin[SP_PPT], nof[SP_PPT];
+    auto fetch = [&](int hp) {
         int hsrc = hp;
-        bool exists = true;
-        if (!ADJ) hsrc = reflect(hp, a.H); else exists = hp >= 0 && hp < a.H;
-        float v[SP_PPT];
+        bool exists = hp < hhi;
+        if (!ADJ) hsrc = reflect(hp, a.H); else exists = exists && hp >= 0 && hp < a.H;
 #pragma unroll
         for (int i = 0; i < SP_PPT; ++i) {
-            v[i] = 0.f;
+            nin[i] = 0.f; nof[i] = 0.f;
             if (pok[i] && exists) {
                 const int64_t off = (int64_t)hsrc * plane_stride + t + nth * i;
-                if (!ADJ) v[i] = inb[off];
-                else { const float o = ofb[off]; v[i] = inb[off] / m - (o == 1.0f ? corr : 0.f); }
+                nin[i] = inb[off];
+                if (ADJ) nof[i] = ofb[off];
             }
         }
+    };
+    fetch(hlo);
+    for (int hp = hlo; hp < hhi; ++hp) {
+        float v[SP_PPT];
+#pragma unroll
+        for (int i = 0; i < SP_PPT; ++i) v[i] = ADJ ? (nin[i] / m - (nof[i] == 1.0f ? corr : 0.f)) : nin[i];
+        fetch(hp + 1);
         // ---- T stencil inside the plane
         if (doT) {
-            __syncthreads();   // previous plane's readers of bufA are done
+            lds_barrier();   // previous plane's readers of bufA are done
 #pragma unroll
             for (int i = 0; i < SP_PPT; ++i) if (pok[i]) bufA[t + nth * i] = v[i];
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < SP_PPT; ++i) {
                 float acc = 0.f;
@@ -256,10 +270,10 @@ __global__ __launch_bounds__(NT) void smooth_plane(PlaneArgs a) {
         }
         // ---- W stencil inside the plane (stride C along the contiguous W*C axis)
         if (doW) {
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < SP_PPT; ++i) if (pok[i]) bufB[t + nth * i] = v[i];
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < SP_PPT; ++i) {
                 float acc = 0.f;
