@@ -12,6 +12,7 @@
 #include "common.h"
 #include <math.h>
 #include <float.h>
+#include <stdlib.h>
 
 namespace kccot {
 
@@ -483,7 +484,9 @@ extern "C" int kccot_smooth_bwd_f32(const float* gout, const float* out, const f
     if ((rc = launch_status("maxnorm_bwd_partial"))) return rc;
     hipLaunchKernelGGL(maxnorm_bwd_combine, dim3(1), dim3(1024), 0, st, (const float*)pdot, (const float*)pcnt, nb, res);
     if ((rc = launch_status("maxnorm_bwd_combine"))) return rc;
-    if (plane_eligible(T, W, C, radius, na)) {   // fused adjoint: ds formed at load time
+    // The fused adjoint (smooth_plane<R,true>) is correct but measured slower than the per-axis
+    // chain at the configs[1] shape (r01: 3-D fwd+bwd 524 us vs 402 us); opt-in until it is tuned.
+    if (plane_eligible(T, W, C, radius, na) && getenv("KCCOT_SMOOTH_FUSED_BWD")) {
         PlaneArgs pa{};
         pa.in = gout; pa.out_fwd = out; pa.out = din; pa.mx = max_in; pa.res = res;
         pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C; pa.axes = flags; pa.tp = tp;
