@@ -99,6 +99,27 @@ def all_gather_cat(t, group=None):
     return out
 
 
+class _AllGatherLocalGrad(torch.autograd.Function):
+    """all-gather whose backward hands back the LOCAL slice of the incoming gradient.  For a
+    quantity every rank computes identically from the gathered tensor (replicated loss) that slice
+    is the partial derivative through this rank's samples; the parameter-gradient all-reduce SUM
+    completes it."""
+
+    @staticmethod
+    def forward(ctx, t, group):
+        ctx.cfg = (dist.get_rank(group), t.shape[0])
+        return all_gather_cat(t, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        rank, Bl = ctx.cfg
+        return g[rank * Bl:(rank + 1) * Bl].contiguous(), None
+
+
+def all_gather_local_grad(t, group=None):
+    return _AllGatherLocalGrad.apply(t, group)
+
+
 class _ShardedLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, real_l, fake_l, h_fake_l, h_real_l, m_real_l, m_fake_l, sc, eps, L, group, ops):

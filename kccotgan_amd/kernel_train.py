@@ -1,0 +1,151 @@
+"""The reference's training-step API (kernel_train.py:219-292) on PyTorch-ROCm + the HIP loss path.
+
+``KCCOTTrainer.disc_training_step(real_in, real_pred, sigma) -> pM`` and
+``gen_training_step(real_in, real_pred, sigma) -> loss`` keep the closures' names, arguments and
+return values; the body is the reference's: sample z, run encoder/decoder, concatenate context and
+prediction along time (kernel_train.py:222-227), optional kernel smoothing of real and fake
+(:229-239), the two discriminators on both (:241-245), ``compute_sinkhorn_loss`` with the
+reference's argument order (:247-248), ``disc_loss = -loss + pM`` (:250), Adam(beta1=0.5,
+beta2=0.9) on (D_h, D_m) resp. (encoder, decoder) (:62-63,252-255,289-291) with the WarmUp +
+staircase ExponentialDecay schedule (:54-59, data_utils.py:589-621).
+
+Data-parallel use (one process per GPU, torch.distributed over RCCL): pass ``group``; each rank
+feeds its shard of the batch, the loss is the GLOBAL-batch divergence assembled by
+``kccotgan_amd.dist`` and parameter gradients are all-reduced with SUM (the loss is replicated,
+each rank holds the partial derivative through its own samples).
+
+Out of scope: the dataset loaders, CLI, logging and checkpoint code of
+``train(args)``.
+"""
+import torch
+import torch.distributed as dist
+
+from . import gan, gan_utils
+from .data_utils import KernelSmoothing
+
+
+def warmup_exponential_decay(step, base_lr, warmup_steps=10000, decay_steps=5000, decay_rate=0.975):
+    """data_utils.py:589-621 WarmUp around kernel_train.py:57 ExponentialDecay(staircase=True)."""
+    if step < warmup_steps:
+        return base_lr * (step / warmup_steps)
+    return base_lr * decay_rate ** ((step - warmup_steps) // decay_steps)
+
+
+class KCCOTTrainer:
+    def __init__(self, batch_size, total_time_steps=15, int_time_steps=5, x_height=64, x_width=64, channels=3,
+                 g_state_size=8, d_state_size=8, g_filter_size=8, d_filter_size=8, z_channels=128, bn=True,
+                 lr=5e-4, warmup=10000, sinkhorn_eps=0.8, sinkhorn_l=100, scaling_coef=15.0, reg_penalty=1.0,
+                 kernel="none", device="cuda", seed=1, group=None):
+        # defaults = kernel_train.py:363-409
+        torch.manual_seed(seed)
+        self.batch_size, self.device, self.group = batch_size, torch.device(device), group
+        self.int_time_steps = int_time_steps
+        self.pred_time_steps = total_time_steps - int_time_steps
+        self.z_shape = (batch_size, self.pred_time_steps, 4, 4, z_channels)     # kernel_train.py:135-136,220
+        self.scaling_coef = 1.0 / scaling_coef                                  # kernel_train.py:71
+        self.sinkhorn_eps, self.sinkhorn_l, self.reg_penalty = sinkhorn_eps, sinkhorn_l, reg_penalty
+        self.kernel_choice = kernel
+        self.gaussian_kernel = KernelSmoothing(temporal_kernel_size=6, spatial_kernel_size=6)   # :216
+        mk = dict(z_width=4, z_height=4, bn=bn, nchannel=channels)
+        self.context_encoder = gan.VideoEncoderConvLSTM(batch_size, int_time_steps, self.pred_time_steps, g_state_size,
+                                                        x_width, x_height, filter_size=g_filter_size, **mk).to(self.device)
+        self.decoder = gan.VideoDecoderConvLSTM(batch_size, int_time_steps, self.pred_time_steps, g_state_size, x_width,
+                                                x_height, filter_size=g_filter_size, z_channels=z_channels,
+                                                **mk).to(self.device)
+        self.discriminator_h = gan.VideoDiscriminator(batch_size, total_time_steps, d_state_size, x_width, x_height,
+                                                      filter_size=d_filter_size, **mk).to(self.device)
+        self.discriminator_m = gan.VideoDiscriminator(batch_size, total_time_steps, d_state_size, x_width, x_height,
+                                                      filter_size=d_filter_size, **mk).to(self.device)
+        self.g_params = list(self.context_encoder.parameters()) + list(self.decoder.parameters())
+        self.d_params = list(self.discriminator_h.parameters()) + list(self.discriminator_m.parameters())
+        self.gen_optimiser = torch.optim.Adam(self.g_params, lr=lr, betas=(0.5, 0.9), eps=1e-7)
+        self.dischm_optimiser = torch.optim.Adam(self.d_params, lr=lr, betas=(0.5, 0.9), eps=1e-7)
+        self.base_lr, self.warmup = lr, warmup
+        self.g_steps = self.d_steps = 0
+        if group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            for p in self.g_params + self.d_params:                              # identical replicas
+                dist.broadcast(p.data, src=0, group=group)
+
+    # ------------------------------------------------------------------ the shared forward
+    def _forward(self, real_in, real_pred, sigma, generator_grad=True):
+        hidden_z = torch.randn(self.z_shape, device=self.device)                 # kernel_train.py:220,260
+        real_inp = torch.cat((real_in, real_pred), dim=2)                        # :222
+        # the discriminator step differentiates w.r.t. D_h / D_m only (:252): no generator tape there
+        with torch.set_grad_enabled(generator_grad):
+            preds_features = self.context_encoder(real_inp)                      # :223
+            fake_pred = self.decoder(preds_features, hidden_z)                   # :224
+        real = torch.cat((real_in, real_pred), dim=2)                            # :226
+        fake = torch.cat((real_in, fake_pred), dim=2)                            # :227
+        if self.kernel_choice == "1d":                                           # :229-239
+            real = self.gaussian_kernel.temporal_convolution(real, sigma)
+            fake = self.gaussian_kernel.temporal_convolution(fake, sigma)
+        elif self.kernel_choice == "2d":
+            real = self.gaussian_kernel.spatial_convolution(real, sigma)
+            fake = self.gaussian_kernel.spatial_convolution(fake, sigma)
+        elif self.kernel_choice == "3d":
+            real = self.gaussian_kernel.gaussian_convolution3D(real, sigma)
+            fake = self.gaussian_kernel.gaussian_convolution3D(fake, sigma)
+        h_fake = self.discriminator_h(fake)                                      # :241-245
+        h_real = self.discriminator_h(real)
+        m_real = self.discriminator_m(real)
+        m_fake = self.discriminator_m(fake)
+        if self._world() > 1:
+            from . import dist as kd
+            loss = kd.sharded_sinkhorn_loss(real.detach(), fake, self.scaling_coef, h_fake, m_real, h_real, m_fake,
+                                            group=self.group)
+        else:
+            loss = gan_utils.compute_sinkhorn_loss(real.detach(), fake, self.scaling_coef, self.sinkhorn_eps,
+                                                   self.sinkhorn_l, h_fake, m_real, h_real, m_fake, video=True)  # :247
+        return loss, m_real
+
+    def _world(self):
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _apply(self, optimiser, params, step):
+        if self._world() > 1:
+            flat = torch.cat([p.grad.reshape(-1) if p.grad is not None else p.new_zeros(p.numel()) for p in params])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)         # replicated loss, partial grads
+            off = 0
+            for p in params:
+                n = p.numel()
+                if p.grad is not None:
+                    p.grad.copy_(flat[off:off + n].view_as(p))
+                off += n
+        for g in optimiser.param_groups:
+            g["lr"] = warmup_exponential_decay(step, self.base_lr, self.warmup)
+        optimiser.step()
+
+    # ------------------------------------------------------------------ kernel_train.py:219-256
+    def disc_training_step(self, real_in, real_pred, sigma):
+        self.dischm_optimiser.zero_grad(set_to_none=True)
+        loss, m_real = self._forward(real_in, real_pred, sigma, generator_grad=False)
+        if self._world() > 1:               # pM couples the whole batch (std and mean over b): use the global M
+            from . import dist as kd
+            m_real = kd.all_gather_local_grad(m_real, self.group)
+        pm1 = gan_utils.scale_invariante_martingale_regularization(m_real, self.reg_penalty, self.scaling_coef)   # :249
+        disc_loss = -loss + pm1                                                  # :250
+        grads = torch.autograd.grad(disc_loss, self.d_params, allow_unused=True)
+        for p, g in zip(self.d_params, grads):
+            p.grad = g
+        self.d_steps += 1
+        self._apply(self.dischm_optimiser, self.d_params, self.d_steps)          # :252-255
+        return pm1.detach()                                                      # :256
+
+    # ------------------------------------------------------------------ kernel_train.py:259-292
+    def gen_training_step(self, real_in, real_pred, sigma):
+        self.gen_optimiser.zero_grad(set_to_none=True)
+        loss, _ = self._forward(real_in, real_pred, sigma)
+        grads = torch.autograd.grad(loss, self.g_params, allow_unused=True)      # :289
+        for p, g in zip(self.g_params, grads):
+            p.grad = g
+        self.g_steps += 1
+        self._apply(self.gen_optimiser, self.g_params, self.g_steps)             # :290-291
+        return loss.detach()                                                     # :292
+
+    def train_iteration(self, real_data, sigma=5.0):
+        """One pass of the loop body kernel_train.py:301-314 on a [B,H,T,W,C] batch."""
+        real_inputs = real_data[:, :, :self.int_time_steps]
+        real_preds = real_data[:, :, self.int_time_steps:]
+        pm = self.disc_training_step(real_inputs, real_preds, sigma)
+        loss = self.gen_training_step(real_inputs, real_preds, sigma)
+        return pm, loss

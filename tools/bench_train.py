@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Time the full training iteration (disc step + gen step, kernel_train.py:313-314) at the
+configs[1] shape: B=64, T=30 (5 context + 25 predicted), 64x64x1, filter sizes 8, z 128."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from kccotgan_amd.kernel_train import KCCOTTrainer
+
+
+def run(kernel, iters=3, B=64):
+    tr = KCCOTTrainer(B, total_time_steps=30, int_time_steps=5, x_height=64, x_width=64, channels=1, kernel=kernel,
+                      device="cuda:0")
+    x = torch.rand(B, 64, 30, 64, 1, device="cuda:0")
+    tr.train_iteration(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        pm, loss = tr.train_iteration(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return dict(kernel=kernel, ms_per_train_step=dt * 1e3, train_steps_per_sec=1 / dt, pm=float(pm), loss=float(loss))
+
+
+if __name__ == "__main__":
+    for k in (sys.argv[1:] or ["none", "3d"]):
+        print(json.dumps(run(k)), flush=True)
