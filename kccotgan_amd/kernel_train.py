@@ -41,7 +41,8 @@ class KCCOTTrainer:
         self.batch_size, self.device, self.group = batch_size, torch.device(device), group
         self.int_time_steps = int_time_steps
         self.pred_time_steps = total_time_steps - int_time_steps
-        self.z_shape = (batch_size, self.pred_time_steps, 4, 4, z_channels)     # kernel_train.py:135-136,220
+        # z joins the encoder's level-4 feature map: 4 x 4 at the reference's 64 x 64 frames (kernel_train.py:135-136,220)
+        self.z_shape = (batch_size, self.pred_time_steps, x_height // 16, x_width // 16, z_channels)
         self.scaling_coef = 1.0 / scaling_coef                                  # kernel_train.py:71
         self.sinkhorn_eps, self.sinkhorn_l, self.reg_penalty = sinkhorn_eps, sinkhorn_l, reg_penalty
         self.kernel_choice = kernel
