@@ -122,13 +122,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)"
                              % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # KCCOT_BENCH_BACKEND=gloo rehearses the N>1 path on ONE GPU (all ranks on cuda:0, collectives
+    # staged through the host); the driver's multi-GPU runs use nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("KCCOT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if (backend == "nccl" or local_rank < ndev) else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from kccotgan_amd import gan_utils as G
     inp, t = make_inputs(SHAPE["B"], 0, dev)
@@ -143,6 +151,7 @@ def main():
         step = lambda: loss_step(G, t)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -156,11 +165,15 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        tt = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt)
     ms = el / args.steps * 1e3
-    nits = G.last_info["compute_sinkhorn_loss"].tolist()
+    if world > 1:
+        from kccotgan_amd import dist as kd
+        nits = kd.last_info["nits"].tolist()
+    else:
+        nits = G.last_info["compute_sinkhorn_loss"].tolist()
 
     out = {
         "metric": "sinkhorn_loss_evals_per_sec", "value": args.steps / el, "unit": "loss-evals/s (fwd+bwd)",

@@ -72,7 +72,7 @@ int kccot_pairwise_cost_f32(const float* x, const float* y, int Bx, int By, int6
  * reads `real` and `fake` once:  C3[0] = xy: modified_cost(real, fake, h_fake, m_real)
  *                                C3[1] = xx: modified_cost(real, real, h_real, m_real)
  *                                C3[2] = yy: modified_cost(fake, fake, h_fake, m_fake)
- * C3 is [3,B,B]. */
+ * C3 is [3,B,B].  The four feature pointers may ALL be NULL: plain scaled squared distances. */
 size_t kccot_pairwise_cost3_workspace_bytes(int B, int64_t K);
 int kccot_pairwise_cost3_f32(const float* real, const float* fake, int B, int64_t K, float sc,
                              const float* h_fake, const float* h_real,
@@ -149,6 +149,16 @@ int kccot_martingale_fwd_f32(const float* M, int B, int T, int J, float lam, flo
                              float* pm_out, kccot_stream_t stream);
 int kccot_martingale_bwd_f32(const float* M, int B, int T, int J, float lam, float sc,
                              const float* gpm, float* dM, kccot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * EXTENSION, no reference behaviour (BASELINE.json north_star names a "batch-vs-batch Gaussian
+ * kernel / MMD matrix"; the reference only imports sklearn's rbf_kernel, data_utils.py:16, and never
+ * calls it).  Defined with sklearn.metrics.pairwise.rbf_kernel semantics: K = exp(-gamma * D) on
+ * the plain squared distances D3 = [xy, xx, yy] ([3,B,B], from kccot_pairwise_cost3_f32 with sc = 1
+ * and no features); mmd_out = mean(Kxx) + mean(Kyy) - 2 mean(Kxy).  K3_out [3,B,B] optional.
+ * ------------------------------------------------------------------------------------------- */
+int kccot_rbf_mmd_f32(const float* D3, int B, float gamma, float* K3_out, float* mmd_out,
+                      kccot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel smoothing.  Replaces KernelSmoothing.temporal_convolution (data_utils.py:503-521,

@@ -282,8 +282,11 @@ extern "C" int kccot_pairwise_cost3_f32(const float* real, const float* fake, in
                                         const float* h_fake, const float* h_real, const float* m_real,
                                         const float* m_fake, int T, int J, unsigned flags, float* C3,
                                         void* ws, size_t ws_bytes, kccot_stream_t stream) {
-    if (!real || !fake || !C3 || !h_fake || !h_real || !m_real || !m_fake)
-        return fail(KCCOT_EINVAL, "pairwise_cost3: null pointer");
+    if (!real || !fake || !C3) return fail(KCCOT_EINVAL, "pairwise_cost3: null pointer");
+    const int nfeat = (h_fake != nullptr) + (h_real != nullptr) + (m_real != nullptr) + (m_fake != nullptr);
+    if (nfeat != 0 && nfeat != 4)   // all four (the loss) or none (plain squared distances, e.g. for the RBF kernel)
+        return fail(KCCOT_EINVAL, "pairwise_cost3: give all of h_fake, h_real, m_real, m_fake or none");
+    if (nfeat == 0) { T = 1; J = 1; }
     if (B <= 0 || K <= 0 || T < 1 || J < 1)
         return fail(KCCOT_EINVAL, "pairwise_cost3: bad shape B=%d K=%lld T=%d J=%d", B, (long long)K, T, J);
     const int64_t bb = (int64_t)B * B;

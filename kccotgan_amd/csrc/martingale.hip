@@ -80,9 +80,43 @@ __global__ __launch_bounds__(1024) void martingale_bwd(const float* __restrict__
     }
 }
 
+// Extension named by the north star, NOT reference behaviour (the reference only imports
+// sklearn's rbf_kernel and never calls it, data_utils.py:16): K = exp(-gamma * D) on the three
+// plain squared-distance matrices D3 = [xy, xx, yy] and the biased MMD^2 estimate
+// mean(Kxx) + mean(Kyy) - 2 mean(Kxy).  One workgroup; sums in fp64, fixed order.
+__global__ __launch_bounds__(1024) void rbf_mmd(const float* __restrict__ D3, int B, float gamma,
+                                                float* __restrict__ K3, float* __restrict__ mmd_out) {
+    __shared__ double part[3][16];
+    const int n = B * B, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double tot[3];
+    for (int p = 0; p < 3; ++p) {
+        double s = 0.0;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const float k = expf(-gamma * D3[(int64_t)p * n + e]);
+            if (K3) K3[(int64_t)p * n + e] = k;
+            s += (double)k;
+        }
+        s = wave_sum_d(s);
+        if (lane == 0) part[p][wid] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int p = 0; p < 3; ++p) { tot[p] = 0.0; for (int w = 0; w < 16; ++w) tot[p] += part[p][w]; }
+        mmd_out[0] = (float)((tot[1] + tot[2] - 2.0 * tot[0]) / (double)n);
+    }
+}
+
 }  // namespace kccot
 
 using namespace kccot;
+
+extern "C" int kccot_rbf_mmd_f32(const float* D3, int B, float gamma, float* K3_out, float* mmd_out,
+                                 kccot_stream_t stream) {
+    if (!D3 || !mmd_out) return fail(KCCOT_EINVAL, "rbf_mmd: null pointer");
+    if (B <= 0 || !(gamma > 0.f)) return fail(KCCOT_EINVAL, "rbf_mmd: bad arguments B=%d gamma=%g", B, (double)gamma);
+    hipLaunchKernelGGL(rbf_mmd, dim3(1), dim3(1024), 0, (hipStream_t)stream, D3, B, gamma, K3_out, mmd_out);
+    return launch_status("rbf_mmd");
+}
 
 static int martingale_check(const float* M, int B, int T, int J, size_t* lds) {
     if (!M) return fail(KCCOT_EINVAL, "martingale: null pointer");

@@ -28,6 +28,8 @@ from ._lib import lib, check, ptr, stream_of, workspace
 _THRESH = 10 ** (-2)
 _LMIN = 100
 
+last_info = {}   # executed Sinkhorn iteration counts of the latest sharded evaluation (device tensor)
+
 
 class HipOps:
     """The four device operations of the sharded path, through the C-ABI."""
@@ -136,9 +138,10 @@ class _ShardedLoss(torch.autograd.Function):
                            ops.cost_rows(fake_l, fake, h_fake_l, m_fake, sc)], dim=0)            # [3,Bl,B]
         C3 = all_gather_cat(blk.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()  # [3,B,B]
         cost3, saved = ops.sinkhorn3_fwd(C3, eps, L)
+        if ops is HipOps:
+            last_info["nits"] = saved[3]
         ctx.saved_state = (saved, real, fake, h_fake, h_real, m_real, m_fake)
         ctx.cfg = (sc, rank * Bl, Bl, ops)
-        ctx.nits = saved[3] if isinstance(saved, tuple) and len(saved) > 3 else None
         return (2.0 * cost3[0] - cost3[1]) - cost3[2]           # gan_utils.py:225
 
     @staticmethod

@@ -423,3 +423,24 @@ def test_smoothing_gradient_matches_autograd():
         b = torch.from_numpy(v).to(DEV).requires_grad_(True)
         (fn(b, 2.0) * torch.from_numpy(wgt).to(DEV)).sum().backward()
         np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.numpy(), rtol=0, atol=2e-4 * float(a.grad.abs().max()))
+
+
+# ---------------------------------------------------------------- extension: RBF kernel / MMD (no reference behaviour)
+def test_rbf_mmd_matches_sklearn_definition():
+    from sklearn.metrics.pairwise import rbf_kernel
+    from kccotgan_amd import mmd
+    rng = np.random.default_rng(21)
+    for B, K in ((16, 320), (64, 2048)):
+        x = rng.random((B, K), dtype=np.float32)
+        y = np.clip(x + 0.2 * rng.standard_normal((B, K), dtype=np.float32), 0, 1).astype(np.float32)
+        K3, m = mmd.rbf_kernels(torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV))
+        ref = [rbf_kernel(x.astype(np.float64), y.astype(np.float64)), rbf_kernel(x.astype(np.float64)),
+               rbf_kernel(y.astype(np.float64))]
+        for p in range(3):
+            np.testing.assert_allclose(K3[p].cpu().numpy(), ref[p], rtol=2e-5, atol=1e-7)
+        want = ref[1].mean() + ref[2].mean() - 2 * ref[0].mean()
+        assert abs(float(m) - want) < 1e-5 * max(abs(want), 1e-3)
+        g = 0.01
+        m2 = mmd.rbf_mmd2(torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV), gamma=g)
+        want2 = rbf_kernel(x, x, g).mean() + rbf_kernel(y, y, g).mean() - 2 * rbf_kernel(x, y, g).mean()
+        assert abs(float(m2) - want2) < 1e-5 * max(abs(want2), 1e-3)
