@@ -9,9 +9,11 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("kernel", ["none", "1d", "3d"])
 def test_disc_and_gen_steps_update_their_own_networks(kernel):
     from kccotgan_amd.kernel_train import KCCOTTrainer
-    B, H, W, C, T, iT = 4, 32, 32, 1, 8, 3
-    tr = KCCOTTrainer(B, total_time_steps=T, int_time_steps=iT, x_height=H, x_width=W, channels=C, g_filter_size=2,
-                      d_filter_size=2, z_channels=8, kernel=kernel, warmup=10, device="cuda:0")
+    # the reference's own layer widths and frame size (kernel_train.py:370-372,401-402): the MIOpen
+    # convolution configurations are exactly those of the full-size run, only batch and T are small
+    B, H, W, C, T, iT = 2, 64, 64, 1, 6, 2
+    tr = KCCOTTrainer(B, total_time_steps=T, int_time_steps=iT, x_height=H, x_width=W, channels=C, kernel=kernel,
+                      warmup=10, device="cuda:0")
     x = torch.rand(B, H, T, W, C, device="cuda:0")
     snap = lambda ps: [p.detach().clone() for p in ps]
     g0, d0 = snap(tr.g_params), snap(tr.d_params)
@@ -21,6 +23,5 @@ def test_disc_and_gen_steps_update_their_own_networks(kernel):
     d1 = snap(tr.d_params)
     loss = tr.gen_training_step(x[:, :, :iT], x[:, :, iT:], 5.0)
     assert torch.isfinite(loss) and changed(g0, snap(tr.g_params)) and not changed(d1, snap(tr.d_params))
-    for _ in range(3):
-        pm, loss = tr.train_iteration(x)
+    pm, loss = tr.train_iteration(x)
     assert torch.isfinite(pm) and torch.isfinite(loss)
