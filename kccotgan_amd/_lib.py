@@ -72,7 +72,44 @@ def _load():
 lib = _load()
 
 
+# ---- debugging aid: KCCOT_DEBUG_CANARY=1 surrounds every buffer the wrappers hand to the library
+# (outputs and workspace) with sentinel-filled guard zones and verifies them after every call.
+_CANARY = os.environ.get("KCCOT_DEBUG_CANARY") == "1"
+_GUARD = 4096            # elements on either side
+_SENT = 1234567.0
+_guards = []
+
+
+def empty(shape, dtype=torch.float32, device=None):
+    if not _CANARY:
+        return torch.empty(shape, dtype=dtype, device=device)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    buf = torch.full((n + 2 * _GUARD,), _SENT, dtype=dtype, device=device)
+    _guards.append((buf, n))
+    del _guards[:-400]
+    return buf[_GUARD:_GUARD + n].view(tuple(shape))
+
+
+def empty_like(t):
+    return empty(tuple(t.shape), t.dtype, t.device)
+
+
+def _verify_guards(what):
+    torch.cuda.synchronize()
+    for buf, n in _guards:
+        lo, hi = buf[:_GUARD], buf[_GUARD + n:]
+        if not (bool((lo == _SENT).all()) and bool((hi == _SENT).all())):
+            bad_lo = int((lo != _SENT).sum())
+            bad_hi = int((hi != _SENT).sum())
+            raise KccotError("guard zone overwritten after %s: buffer of %d elements (%s), %d bad below, %d bad above"
+                             % (what, n, buf.dtype, bad_lo, bad_hi))
+
+
 def check(rc, what):
+    if _CANARY:
+        _verify_guards(what)
     if rc == 0:
         return
     msg = lib.kccot_last_error().decode("utf-8", "replace")
@@ -116,6 +153,9 @@ def workspace(nbytes, ref):
     key = (ref.device, stream_of(ref))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=ref.device)
+        if _CANARY:   # float32 view so that the guard sentinel is exact
+            buf = empty((int(nbytes) + 3) // 4, torch.float32, ref.device)
+        else:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=ref.device)
         _ws_cache[key] = buf
-    return buf.data_ptr(), buf.numel()
+    return buf.data_ptr(), int(nbytes) if _CANARY else buf.numel()

@@ -16,8 +16,8 @@ class _Smooth(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sigma, radius, axes):
         B, H, T, W, C = x.shape
-        out = torch.empty_like(x)
-        mx = torch.empty((1,), dtype=torch.float32, device=x.device)
+        out = _lib.empty_like(x)
+        mx = _lib.empty((1,), torch.float32, x.device)
         ws, wsb = workspace(lib.kccot_smooth_workspace_bytes(B, H, T, W, C), x)
         check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, sigma, radius, axes, ptr(out), ptr(mx), ws, wsb,
                                        stream_of(x)), "smooth_fwd")
@@ -31,7 +31,7 @@ class _Smooth(torch.autograd.Function):
         sigma, radius, axes = ctx.cfg
         B, H, T, W, C = out.shape
         g = g.contiguous()
-        din = torch.empty_like(out)
+        din = _lib.empty_like(out)
         ws, wsb = workspace(lib.kccot_smooth_workspace_bytes(B, H, T, W, C), out)
         check(lib.kccot_smooth_bwd_f32(ptr(g), ptr(out), ptr(mx), B, H, T, W, C, sigma, radius, axes, ptr(din),
                                        ws, wsb, stream_of(out)), "smooth_bwd")

@@ -39,7 +39,7 @@ class HipOps:
         Bx, K = x_rows.shape
         By = y_full.shape[0]
         T, J = h_rows.shape[1], h_rows.shape[2]
-        C = torch.empty((Bx, By), dtype=torch.float32, device=x_rows.device)
+        C = _lib.empty((Bx, By), torch.float32, x_rows.device)
         ws, wsb = workspace(lib.kccot_pairwise_cost_workspace_bytes(Bx, By, K), x_rows)
         check(lib.kccot_pairwise_cost_f32(ptr(x_rows), ptr(y_full), Bx, By, K, sc, ptr(h_rows), ptr(M_full), None, None,
                                           T, J, 0, ptr(C), ws, wsb, stream_of(x_rows)), "pairwise_cost")
@@ -50,10 +50,10 @@ class HipOps:
         nprob, n, _ = C3.shape
         dev = C3.device
         Lh = max(int(L), 1)
-        u_hist = torch.empty((nprob, Lh, n), dtype=torch.float32, device=dev)
-        v_hist = torch.empty((nprob, Lh, n), dtype=torch.float32, device=dev)
-        cost = torch.empty((nprob,), dtype=torch.float32, device=dev)
-        nits = torch.empty((nprob,), dtype=torch.int32, device=dev)
+        u_hist = _lib.empty((nprob, Lh, n), torch.float32, dev)
+        v_hist = _lib.empty((nprob, Lh, n), torch.float32, dev)
+        cost = _lib.empty((nprob,), torch.float32, dev)
+        nits = _lib.empty((nprob,), torch.int32, dev)
         ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(nprob, n), C3)
         check(lib.kccot_sinkhorn_fwd_f32(ptr(C3), nprob, n, float(eps), int(L), _LMIN, _THRESH, _lib.STOP_COUNT,
                                          ptr(u_hist), ptr(v_hist), ptr(cost), ptr(nits), None, ws, wsb,
@@ -64,7 +64,7 @@ class HipOps:
     def sinkhorn3_bwd(saved, gcost3):
         C3, u_hist, v_hist, nits, eps, Lh = saved
         nprob, n, _ = C3.shape
-        dC3 = torch.empty_like(C3)
+        dC3 = _lib.empty_like(C3)
         ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(nprob, n), C3)
         check(lib.kccot_sinkhorn_bwd_f32(ptr(C3), ptr(u_hist), ptr(v_hist), ptr(nits), nprob, n, eps, Lh,
                                          ptr(gcost3.contiguous()), ptr(dC3), ws, wsb, stream_of(C3)), "sinkhorn_bwd")
@@ -75,8 +75,8 @@ class HipOps:
         B, K = real.shape
         T, J = h_fake.shape[1], h_fake.shape[2]
         dev = real.device
-        dfake = torch.empty((row_count, K), dtype=torch.float32, device=dev)
-        dhf, dhr, dmr, dmf = (torch.empty((row_count, T, J), dtype=torch.float32, device=dev) for _ in range(4))
+        dfake = _lib.empty((row_count, K), torch.float32, dev)
+        dhf, dhr, dmr, dmf = (_lib.empty((row_count, T, J), torch.float32, dev) for _ in range(4))
         ws, wsb = workspace(lib.kccot_pairwise_cost3_bwd_workspace_bytes(B, K), real)
         check(lib.kccot_pairwise_cost3_bwd_rows_f32(ptr(dC3), ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real),
                                                     ptr(m_real), ptr(m_fake), T, J, row_begin, row_count, ptr(dfake),

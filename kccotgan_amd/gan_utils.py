@@ -71,7 +71,7 @@ class _PairwiseCost(torch.autograd.Function):
                 T, J = h.shape[1], h.shape[2]
         same = _same(x, y)
         flags = (_lib.COST_SAME if same else 0) | cost_flags
-        C = torch.empty((Bx, By), dtype=torch.float32, device=x.device)
+        C = _lib.empty((Bx, By), torch.float32, x.device)
         ws, wsb = workspace(lib.kccot_pairwise_cost_workspace_bytes(Bx, By, K), x)
         check(lib.kccot_pairwise_cost_f32(ptr(x), ptr(y), Bx, By, K, sc, ptr(h1), ptr(M1), ptr(h2), ptr(M2),
                                           T, J, flags, ptr(C), ws, wsb, stream_of(x)), "pairwise_cost")
@@ -90,12 +90,12 @@ class _PairwiseCost(torch.autograd.Function):
         want_x, want_y = need[0], need[1] and not ctx.same
         if ctx.same:
             want_x = need[0] or need[1]
-        dx = torch.empty_like(x) if want_x else None
-        dy = torch.empty_like(y) if want_y else None
-        dh1 = torch.empty_like(h1) if (h1 is not None and need[2]) else None
-        dM1 = torch.empty_like(M1) if (M1 is not None and need[3]) else None
-        dh2 = torch.empty_like(h2) if (h2 is not None and need[4]) else None
-        dM2 = torch.empty_like(M2) if (M2 is not None and need[5]) else None
+        dx = _lib.empty_like(x) if want_x else None
+        dy = _lib.empty_like(y) if want_y else None
+        dh1 = _lib.empty_like(h1) if (h1 is not None and need[2]) else None
+        dM1 = _lib.empty_like(M1) if (M1 is not None and need[3]) else None
+        dh2 = _lib.empty_like(h2) if (h2 is not None and need[4]) else None
+        dM2 = _lib.empty_like(M2) if (M2 is not None and need[5]) else None
         flags = _lib.COST_SAME if ctx.same else 0
         ws, wsb = workspace(lib.kccot_pairwise_cost_bwd_workspace_bytes(Bx, By), x)
         st = stream_of(x)
@@ -125,7 +125,7 @@ class _Cost3(torch.autograd.Function):
         for t in (h_fake, h_real, m_real, m_fake):
             if tuple(t.shape) != (B, T, J):
                 raise ValueError("h / M must all be [%d,%d,%d]; got %s" % (B, T, J, tuple(t.shape)))
-        C3 = torch.empty((3, B, B), dtype=torch.float32, device=real.device)
+        C3 = _lib.empty((3, B, B), torch.float32, real.device)
         ws, wsb = workspace(lib.kccot_pairwise_cost3_workspace_bytes(B, K), real)
         check(lib.kccot_pairwise_cost3_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
                                            ptr(m_fake), T, J, cost_flags, ptr(C3), ws, wsb, stream_of(real)),
@@ -144,11 +144,11 @@ class _Cost3(torch.autograd.Function):
         B, K = real.shape
         T, J = h_fake.shape[1], h_fake.shape[2]
         need = ctx.needs_input_grad
-        dfake = torch.empty_like(fake) if need[1] else None
-        dhf = torch.empty_like(h_fake) if need[2] else None
-        dhr = torch.empty_like(h_real) if need[3] else None
-        dmr = torch.empty_like(m_real) if need[4] else None
-        dmf = torch.empty_like(m_fake) if need[5] else None
+        dfake = _lib.empty_like(fake) if need[1] else None
+        dhf = _lib.empty_like(h_fake) if need[2] else None
+        dhr = _lib.empty_like(h_real) if need[3] else None
+        dmr = _lib.empty_like(m_real) if need[4] else None
+        dmf = _lib.empty_like(m_fake) if need[5] else None
         ws, wsb = workspace(lib.kccot_pairwise_cost3_bwd_workspace_bytes(B, K), real)
         check(lib.kccot_pairwise_cost3_bwd_f32(ptr(g3), ptr(real), ptr(fake), B, K, ctx.sc, ptr(h_fake), ptr(h_real),
                                                ptr(m_real), ptr(m_fake), T, J, ptr(dfake), ptr(dhf), ptr(dhr),
@@ -166,10 +166,10 @@ class _Sinkhorn(torch.autograd.Function):
         dev = C.device
         keep = ctx.needs_input_grad[0]
         Lh = max(int(L), 1)
-        u_hist = torch.empty((nprob, Lh, n), dtype=torch.float32, device=dev) if keep else None
-        v_hist = torch.empty((nprob, Lh, n), dtype=torch.float32, device=dev) if keep else None
-        cost = torch.empty((nprob,), dtype=torch.float32, device=dev)
-        nits = torch.empty((nprob,), dtype=torch.int32, device=dev)
+        u_hist = _lib.empty((nprob, Lh, n), torch.float32, dev) if keep else None
+        v_hist = _lib.empty((nprob, Lh, n), torch.float32, dev) if keep else None
+        cost = _lib.empty((nprob,), torch.float32, dev)
+        nits = _lib.empty((nprob,), torch.int32, dev)
         ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(nprob, n), C)
         check(lib.kccot_sinkhorn_fwd_f32(ptr(C), nprob, n, float(eps), int(L), int(Lmin), _THRESH, stop_mode,
                                          ptr(u_hist), ptr(v_hist), ptr(cost), ptr(nits), None, ws, wsb,
@@ -185,7 +185,7 @@ class _Sinkhorn(torch.autograd.Function):
         C, u_hist, v_hist, nits = ctx.saved_tensors
         nprob, n, _ = C.shape
         gcost = gcost.contiguous().float()
-        dC = torch.empty_like(C)
+        dC = _lib.empty_like(C)
         ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(nprob, n), C)
         check(lib.kccot_sinkhorn_bwd_f32(ptr(C), ptr(u_hist), ptr(v_hist), ptr(nits), nprob, n, ctx.eps, ctx.Lh,
                                          ptr(gcost), ptr(dC), ws, wsb, stream_of(C)), "sinkhorn_bwd")
@@ -197,14 +197,14 @@ class _MixedDivergence(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cost3):
-        loss = torch.empty((1,), dtype=torch.float32, device=cost3.device)
+        loss = _lib.empty((1,), torch.float32, cost3.device)
         check(lib.kccot_mixed_divergence_fwd_f32(ptr(cost3), ptr(loss), stream_of(cost3)), "mixed_divergence_fwd")
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         g = g.reshape(1).contiguous().float()
-        gc = torch.empty((3,), dtype=torch.float32, device=g.device)
+        gc = _lib.empty((3,), torch.float32, g.device)
         check(lib.kccot_mixed_divergence_bwd_f32(ptr(g), ptr(gc), stream_of(g)), "mixed_divergence_bwd")
         return gc
 
@@ -213,7 +213,7 @@ class _Martingale(torch.autograd.Function):
     @staticmethod
     def forward(ctx, M, lam, sc):
         B, T, J = M.shape
-        pm = torch.empty((1,), dtype=torch.float32, device=M.device)
+        pm = _lib.empty((1,), torch.float32, M.device)
         check(lib.kccot_martingale_fwd_f32(ptr(M), B, T, J, lam, sc, ptr(pm), stream_of(M)), "martingale_fwd")
         ctx.save_for_backward(M)
         ctx.lam, ctx.sc = lam, sc
@@ -224,7 +224,7 @@ class _Martingale(torch.autograd.Function):
         (M,) = ctx.saved_tensors
         B, T, J = M.shape
         g = g.reshape(1).contiguous().float()
-        dM = torch.empty_like(M)
+        dM = _lib.empty_like(M)
         check(lib.kccot_martingale_bwd_f32(ptr(M), B, T, J, ctx.lam, ctx.sc, ptr(g), ptr(dM), stream_of(M)),
               "martingale_bwd")
         return dM, None, None

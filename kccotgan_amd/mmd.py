@@ -9,6 +9,7 @@ Forward only.
 """
 import torch
 
+from . import _lib
 from ._lib import lib, check, ptr, stream_of, workspace, require_gpu
 
 
@@ -18,7 +19,7 @@ def _dist3(real, fake):
     fake = fake.reshape(B, -1).float().contiguous()
     require_gpu(real)
     K = real.shape[1]
-    D3 = torch.empty((3, B, B), dtype=torch.float32, device=real.device)
+    D3 = _lib.empty((3, B, B), torch.float32, real.device)
     ws, wsb = workspace(lib.kccot_pairwise_cost3_workspace_bytes(B, K), real)
     check(lib.kccot_pairwise_cost3_f32(ptr(real), ptr(fake), B, K, 1.0, None, None, None, None, 1, 1, 0, ptr(D3),
                                        ws, wsb, stream_of(real)), "pairwise_cost3")
@@ -30,8 +31,8 @@ def rbf_kernels(real, fake, gamma=None):
     D3, K = _dist3(real, fake)
     gamma = float(gamma) if gamma is not None else 1.0 / K          # sklearn default
     B = D3.shape[1]
-    K3 = torch.empty_like(D3)
-    mmd = torch.empty((1,), dtype=torch.float32, device=D3.device)
+    K3 = _lib.empty_like(D3)
+    mmd = _lib.empty((1,), torch.float32, D3.device)
     check(lib.kccot_rbf_mmd_f32(ptr(D3), B, gamma, ptr(K3), ptr(mmd), stream_of(D3)), "rbf_mmd")
     return K3, mmd.reshape(())
 
