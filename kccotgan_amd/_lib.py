@@ -154,7 +154,7 @@ def workspace(nbytes, ref):
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         if _CANARY:   # float32 view so that the guard sentinel is exact
-            buf = empty((int(nbytes) + 3) // 4, torch.float32, ref.device)
+            buf = empty(((int(nbytes) + 3) // 4,), torch.float32, ref.device)
         else:
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=ref.device)
         _ws_cache[key] = buf
