@@ -219,6 +219,139 @@ __global__ __launch_bounds__(256) void gram128_partial(GramArgs ga) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Same stacked Gram, all ten sub-tiles, on the bf16 MFMA pipe with an EXACT three-way split.
+//
+// Every fp32 value is cut into three bf16 pieces by truncation, x = h + m + l exactly (8 + 8 + 8
+// significand bits: h = top half of the word, m = top half of x - h, l = x - h - m), while the
+// tile is staged; the Gram entry is accumulated in fp32 as
+//     sum_k  xh*yh + (xh*ym + xm*yh) + (xh*yl + xl*yh + xm*ym)
+// -- six v_mfma_f32_32x32x16_bf16 per 16 k instead of eight v_mfma_f32_32x32x2_f32, each of them
+// four times shorter in issue cycles per k: the f32-MFMA-bound kernel becomes HBM-bound.  bf16 x
+// bf16 products are exact in fp32; the dropped terms xm*yl + xl*ym + xl*yl are below 2^-24 of
+// |x*y|, i.e. under the rounding of the fp32 accumulation itself, so this is fp32 arithmetic to
+// working precision (parity tests run both kernels against the same golden vectors).
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int XKT = 64;                         // floats of K per stage
+constexpr int XPITCH = XKT * 2 + 16;            // bytes per row of one bf16 plane (+16: conflict-free b128 reads)
+constexpr int XPLANE = GRAM_ROWS * XPITCH;      // 18432 bytes
+
+__device__ __forceinline__ void split3_store(unsigned char* zs, int byte_off, float4 v) {
+    const unsigned x[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    unsigned m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float h = __uint_as_float(x[i] & 0xFFFF0000u);
+        const float r1 = __uint_as_float(x[i]) - h;                        // exact
+        const float mm = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+        m[i] = __float_as_uint(r1);
+        l[i] = __float_as_uint(r1 - mm);                                   // exact, <= 8 significant bits
+    }
+    // pack the upper halves of consecutive elements: dword = bf16(e0) | bf16(e1) << 16
+    uint2 ph, pm, pl;
+    ph.x = __builtin_amdgcn_perm(x[1], x[0], 0x07060302u); ph.y = __builtin_amdgcn_perm(x[3], x[2], 0x07060302u);
+    pm.x = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); pm.y = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+    pl.x = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u); pl.y = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+    *reinterpret_cast<uint2*>(zs + byte_off) = ph;
+    *reinterpret_cast<uint2*>(zs + XPLANE + byte_off) = pm;
+    *reinterpret_cast<uint2*>(zs + 2 * XPLANE + byte_off) = pl;
+}
+
+#define KCCOT_X3(ACC, AOFF, BOFF)                                                               \
+    {                                                                                           \
+        const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(zs + (AOFF));                        \
+        const bf16x8 Am = *reinterpret_cast<const bf16x8*>(zs + XPLANE + (AOFF));               \
+        const bf16x8 Al = *reinterpret_cast<const bf16x8*>(zs + 2 * XPLANE + (AOFF));           \
+        const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(zs + (BOFF));                        \
+        const bf16x8 Bm = *reinterpret_cast<const bf16x8*>(zs + XPLANE + (BOFF));               \
+        const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(zs + 2 * XPLANE + (BOFF));           \
+        /* smallest terms first */                                                              \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, ACC, 0, 0, 0);                    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, ACC, 0, 0, 0);                    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, ACC, 0, 0, 0);                    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, ACC, 0, 0, 0);                    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, ACC, 0, 0, 0);                    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, ACC, 0, 0, 0);                    \
+    }
+
+__global__ __launch_bounds__(256) void gram128_partial_x3(GramArgs ga) {
+    __shared__ __attribute__((aligned(16))) unsigned char zs[3 * XPLANE];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t kbeg = (int64_t)blockIdx.x * ga.chunk;
+    const int64_t kend = (kbeg + ga.chunk < ga.K) ? kbeg + ga.chunk : ga.K;
+    if (kbeg >= kend) return;
+
+    // staging: thread holds the float4 at columns c4..c4+3 of stack rows r0 + 16 j (j < 4: src1,
+    // j >= 4: src2 row r0 + 16 (j-4)) -- row i of both tensors in one thread, for E = src2 - src1
+    const int r0 = t >> 4, c4 = (t & 15) * 4;
+    const float* rp[8];
+    bool ok[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = r0 + 16 * (j & 3);
+        ok[j] = r < (j < 4 ? ga.n1 : ga.n2);
+        rp[j] = (j < 4 ? ga.src1 : ga.src2) + (int64_t)r * ga.K;
+    }
+    const WaveWork ww = wave_work(0x3FFu, wave);
+    const int lo = (lane & 31) * XPITCH + 16 * (lane >> 5);     // row (lane&31), k half (lane>>5) of a 16-k block
+    const int a0 = ww.a[0] * 32 * XPITCH + lo, b0 = ww.b[0] * 32 * XPITCH + lo;
+    const int a1 = ww.a[1] * 32 * XPITCH + lo, b1 = ww.b[1] * 32 * XPITCH + lo;
+    const int a2 = ww.a[2] * 32 * XPITCH + lo, b2 = ww.b[2] * 32 * XPITCH + lo;
+    const int half = (wave & 1) * 2;                            // k-blocks of the split sub-tile
+
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kbeg + c4, kend, ok[j]);
+
+    for (int64_t k0 = kbeg; k0 < kend; k0 += XKT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ga.pair_diff) {
+                v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
+            }
+            split3_store(zs, (r0 + 16 * j) * XPITCH + c4 * 2, v[j]);
+            split3_store(zs, (64 + r0 + 16 * j) * XPITCH + c4 * 2, v[j + 4]);
+        }
+        __syncthreads();
+        const int64_t kn = k0 + XKT;
+        if (kn < kend) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kn + c4, kend, ok[j]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            KCCOT_X3(acc0, a0 + kb * 32, b0 + kb * 32)
+            KCCOT_X3(acc1, a1 + kb * 32, b1 + kb * 32)
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            KCCOT_X3(acc2, a2 + (half + g) * 32, b2 + (half + g) * 32)
+        }
+        __syncthreads();
+    }
+
+    float* base = ga.gpart + (int64_t)blockIdx.x * GRAM_SLABS * 1024;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    {
+        float* o = base + ww.slab[0] * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc0[r];
+        o = base + ww.slab[1] * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc1[r];
+        o = base + ww.slab[2] * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc2[r];
+    }
+}
+
 // Sum the per-chunk partial Gram sub-tiles in fp64.  One workgroup of 1024 threads owns 64
 // consecutive Gram entries (one 256-byte line per chunk): thread (e = t & 63, grp = t >> 6) adds
 // chunks grp, grp+16, ... in increasing order, then the 16 group sums are combined in fixed order
@@ -340,14 +473,20 @@ static int gram_target_wgs() {
     return v > 0 ? v : 256;
 }
 
+static bool gram_use_x3() {
+    const char* e = getenv("KCCOT_GRAM_F32");   // =1: keep the f32-input MFMA kernel (A/B and parity runs)
+    return !(e && atoi(e) == 1);
+}
+
 GramPlan plan_gram(int64_t K) {
     GramPlan pl{};
-    const int64_t ksteps = (K + GRAM_KT - 1) / GRAM_KT;
+    // chunks are multiples of the larger stage (64) so that either kernel can run the plan
+    const int64_t ksteps = (K + XKT - 1) / XKT;
     int64_t nchunk = gram_target_wgs();
     if (nchunk > ksteps) nchunk = ksteps;
     if (nchunk < 1) nchunk = 1;
     const int64_t spc = (ksteps + nchunk - 1) / nchunk;
-    pl.chunk = spc * GRAM_KT;
+    pl.chunk = spc * XKT;
     pl.nchunk = (int)((K + pl.chunk - 1) / pl.chunk);
     // sized for the largest plan the knob can produce so that the query stays an upper bound
     int64_t max_chunks = ksteps < 1024 ? ksteps : 1024;
@@ -404,7 +543,8 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     ga.K = K; ga.chunk = pl.chunk;
     ga.gpart = static_cast<float*>(ws);
     double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.gpart_bytes);
-    if (ga.mask == 0x3FFu) hipLaunchKernelGGL(gram128_partial<true>, dim3(pl.nchunk), dim3(256), 0, st, ga);
+    if (ga.mask == 0x3FFu && gram_use_x3()) hipLaunchKernelGGL(gram128_partial_x3, dim3(pl.nchunk), dim3(256), 0, st, ga);
+    else if (ga.mask == 0x3FFu) hipLaunchKernelGGL(gram128_partial<true>, dim3(pl.nchunk), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL(gram128_partial<false>, dim3(pl.nchunk), dim3(256), 0, st, ga);
     int rc = launch_status("gram128_partial");
     if (rc || partial_only) return rc;

@@ -55,15 +55,19 @@ def flat(v):
     return v.permute(0, 2, 1, 3, 4).reshape(v.shape[0], v.shape[2], -1).contiguous()
 
 
-PATHS = ["auto", "direct", "mfma"]
+# "mfma" = the default MFMA kernels (bf16 exact-split for full stacks, f32-input otherwise);
+# "mfma_f32" forces the f32-input MFMA kernel everywhere (KCCOT_GRAM_F32=1)
+PATHS = ["auto", "direct", "mfma", "mfma_f32"]
 
 
 def set_path(G, L, path, K=None):
     """Select the cost kernel.  The MFMA path needs K % 4 == 0 and K >= 32 (one k-tile); the
     'tiny' golden shape (K = 24) is below that and only runs the direct kernel."""
-    if path == "mfma" and K is not None and (K % 4 != 0 or K < 32):
+    if path.startswith("mfma") and K is not None and (K % 4 != 0 or K < 32):
         pytest.skip("MFMA path not eligible for K=%d" % K)
-    G.cost_flags = {"auto": 0, "direct": L.COST_FORCE_DIRECT, "mfma": L.COST_FORCE_MFMA}[path]
+    os.environ["KCCOT_GRAM_F32"] = "1" if path == "mfma_f32" else "0"
+    G.cost_flags = {"auto": 0, "direct": L.COST_FORCE_DIRECT, "mfma": L.COST_FORCE_MFMA,
+                    "mfma_f32": L.COST_FORCE_MFMA}[path]
 
 
 def kdim(shape):
@@ -75,6 +79,7 @@ def kdim(shape):
 def _reset_flags(G):
     yield
     G.cost_flags = 0
+    os.environ["KCCOT_GRAM_F32"] = "0"
 
 
 # ---------------------------------------------------------------- cost matrices
@@ -301,7 +306,7 @@ def test_full_size_properties(G, L):
     assert rel(permuted, base) < 2e-5
     # translation invariance of the l2 cost, linearity in scaling_coef, zero diagonal / symmetry
     x, y = t["real"].reshape(B, -1), t["fake"].reshape(B, -1)
-    for path in ("direct", "mfma"):
+    for path in ("direct", "mfma", "mfma_f32"):
         set_path(G, L, path)
         C = G.cost_xy(x, y, cases.SC)
         C2 = G.cost_xy(x, y, 2 * cases.SC)
