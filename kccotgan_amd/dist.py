@@ -41,8 +41,12 @@ class HipOps:
         T, J = h_rows.shape[1], h_rows.shape[2]
         C = _lib.empty((Bx, By), torch.float32, x_rows.device)
         ws, wsb = workspace(lib.kccot_pairwise_cost_workspace_bytes(Bx, By, K), x_rows)
+        # row blocks pair sample i with ALL samples j, so the pair-difference stack of the fused
+        # single-GPU kernel does not apply; the direct-difference kernel keeps the small distances of
+        # the GAN regime exact (a rank only builds B/G rows, the VALU rate is ample)
         check(lib.kccot_pairwise_cost_f32(ptr(x_rows), ptr(y_full), Bx, By, K, sc, ptr(h_rows), ptr(M_full), None, None,
-                                          T, J, 0, ptr(C), ws, wsb, stream_of(x_rows)), "pairwise_cost")
+                                          T, J, _lib.COST_FORCE_DIRECT, ptr(C), ws, wsb, stream_of(x_rows)),
+              "pairwise_cost")
         return C
 
     @staticmethod

@@ -79,7 +79,7 @@ def test_sharded_hip_equals_single_gpu(shape, seed, regime, tmp_path):
     B = inp["real"].shape[0]
     Bl = B // 2
     for r, out in enumerate(res):
-        assert abs(float(out["loss"]) - float(ref)) <= 1e-6 * abs(float(ref))
+        assert abs(float(out["loss"]) - float(ref)) <= 2e-6 * abs(float(ref))
         for k, g in zip(NAMES, grads):
             g = g.cpu().double().numpy()
             want = g.reshape(B, -1)[r * Bl:(r + 1) * Bl]

@@ -10,12 +10,12 @@ run() {
 import json,sys
 d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 r=d["roofline"]
-print("%-22s ms/step %.4f  cost-kernel %.1f us  cost-stage %.1f us  mfma-frac %.3f" % (sys.argv[1], d["ms_per_step"], r["kernel_us"], r["cost_stage_us"], r["frac"]))
+print("%-22s ms/step %.4f  cost-kernel %.1f us  cost-stage %.1f us  hbm-frac %.3f" % (sys.argv[1], d["ms_per_step"], r["kernel_us"], r["cost_stage_us"], r["hbm_frac"]))
 PY
 }
 for rep in 1 2; do
 run default_$rep A=1 &&
-run sk_lpr4_$rep KCCOT_SK_LPR=4 &&
-run sk_lpr8_$rep KCCOT_SK_LPR=8 &&
-run sk_lpr16_$rep KCCOT_SK_LPR=16 || exit 1
+run wgs480_$rep KCCOT_GRAM_WGS=480 &&
+run wgs720_$rep KCCOT_GRAM_WGS=720 &&
+run f32_$rep KCCOT_GRAM_F32=1 || exit 1
 done
