@@ -189,20 +189,30 @@ def main():
         B, T, J = SHAPE["B"], SHAPE["T"], SHAPE["J"]
         alg_bytes = 2 * B * K * 4 + 16 * B * T * J + 12 * B * B            # read real+fake once
         alg_flops = 4 * B * B * K                                          # xy full + xx, yy triangles (8(d))
-        exec_flops = 10 * 2 * 32 * 32 * K                                  # ten 32x32 Gram sub-tiles on the MFMA pipe
+        f32_path = os.environ.get("KCCOT_GRAM_F32") == "1"
         t_s = kt["partial"] * 1e-6
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             traffic = json.load(open(tf)).get("gram128_partial_bytes_per_launch")
-        out["roofline"] = {
-            "kernel": "gram128_partial", "bound": "mfma", "achieved": alg_flops / t_s / 1e12,
-            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flops / t_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
-            "traffic": traffic, "kernel_us": kt["partial"], "cost_stage_us": kt["stage"],
-            "executed_mfma_tflops": exec_flops / t_s / 1e12,
-            "hbm_achieved_GBs": alg_bytes / t_s / 1e9, "hbm_frac": alg_bytes / t_s / 1e9 / HBM_PEAK_GBS,
-            "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
-        }
+        hbm = alg_bytes / t_s / 1e9
+        if f32_path:
+            # f32-input MFMA kernel: ideal 12.8 us on the MFMA pipe vs 7.9 us of HBM -> MFMA-bound
+            exec_flops = 10 * 2 * 32 * 32 * K
+            roof = {"kernel": "gram128_partial<f32 MFMA>", "bound": "mfma", "achieved": alg_flops / t_s / 1e12,
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flops / t_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "executed_mfma_tflops": exec_flops / t_s / 1e12}
+        else:
+            # exact three-way bf16 split on the bf16 MFMA pipe: 6 x 10 sub-tiles x 2*32*32*K flops = 15.1 GFLOP,
+            # ideal 6.0 us at the 2.5 PFLOP/s dense bf16 peak vs 7.9 us of HBM -> HBM-bound
+            exec_flops = 6 * 10 * 2 * 32 * 32 * K
+            roof = {"kernel": "gram128_partial_x3", "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm / HBM_PEAK_GBS, "executed_bf16_mfma_tflops": exec_flops / t_s / 1e12,
+                    "bf16_mfma_frac": exec_flops / t_s / 1e12 / 2500.0}
+        roof.update({"traffic": traffic, "kernel_us": kt["partial"], "cost_stage_us": kt["stage"],
+                     "hbm_achieved_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
+                     "algorithmic_flops": alg_flops})
+        out["roofline"] = roof
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(inp)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
