@@ -352,6 +352,100 @@ __global__ __launch_bounds__(256) void gram128_partial_x3(GramArgs ga) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Wave-specialised form of the x3 kernel: 8 waves per workgroup, two per SIMD.  Waves 0-3 are
+// PRODUCERS (global loads, E = src2 - src1, three-way split, ds_write into the next LDS buffer),
+// waves 4-7 are CONSUMERS (ds_read + the 60 bf16 MFMAs of the stage on the current buffer).  The
+// matrix pipe and the VALU are separate pipes of a SIMD, so a producer wave and a consumer wave
+// that share a SIMD run concurrently: the staging no longer sits between the MFMA phases of the
+// same wave.  One s_barrier per stage (every wave executes the same number of them).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
+    __shared__ __attribute__((aligned(16))) unsigned char zsA[3 * XPLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char zsB[3 * XPLANE];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t kbeg = (int64_t)blockIdx.x * ga.chunk;
+    const int64_t kend = (kbeg + ga.chunk < ga.K) ? kbeg + ga.chunk : ga.K;
+    if (kbeg >= kend) return;
+    const int nstage = (int)((kend - kbeg + XKT - 1) / XKT);
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ producers
+        const int r0 = t >> 4, c4 = (t & 15) * 4;
+        const float* rp[8];
+        bool ok[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + 16 * (j & 3);
+            ok[j] = r < (j < 4 ? ga.n1 : ga.n2);
+            rp[j] = (j < 4 ? ga.src1 : ga.src2) + (int64_t)r * ga.K;
+        }
+        const int wbase = r0 * XPITCH + c4 * 2;
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kbeg + c4, kend, ok[j]);
+        for (int s = 0; s <= nstage; ++s) {
+            // stage s goes into buffer s&1 (the consumers read it during iteration s+1 of this loop)
+            if (s < nstage) {
+                unsigned char* zb = (s & 1) ? zsB : zsA;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ga.pair_diff) {
+                        v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
+                    }
+                    split3_store(zb, wbase + 16 * j * XPITCH, v[j]);
+                    split3_store(zb, wbase + (64 + 16 * j) * XPITCH, v[j + 4]);
+                }
+                const int64_t kn = kbeg + (int64_t)(s + 1) * XKT;
+                if (s + 1 < nstage) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kn + c4, kend, ok[j]);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const WaveWork ww = wave_work(0x3FFu, wave - 4);
+    const int lo = (lane & 31) * XPITCH + 16 * (lane >> 5);
+    const int a0 = ww.a[0] * 32 * XPITCH + lo, b0 = ww.b[0] * 32 * XPITCH + lo;
+    const int a1 = ww.a[1] * 32 * XPITCH + lo, b1 = ww.b[1] * 32 * XPITCH + lo;
+    const int a2 = ww.a[2] * 32 * XPITCH + lo, b2 = ww.b[2] * 32 * XPITCH + lo;
+    const int half = ((wave - 4) & 1) * 2;
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+    __syncthreads();                                  // stage 0 is in buffer A
+    for (int s = 0; s < nstage; ++s) {
+        const unsigned char* zs = (s & 1) ? zsB : zsA;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            KCCOT_X3(acc0, a0 + kb * 32, b0 + kb * 32)
+            KCCOT_X3(acc1, a1 + kb * 32, b1 + kb * 32)
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            KCCOT_X3(acc2, a2 + (half + g) * 32, b2 + (half + g) * 32)
+        }
+        __syncthreads();                              // stage s consumed; stage s+1 is complete
+    }
+    float* base = ga.gpart + (int64_t)blockIdx.x * GRAM_SLABS * 1024;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    float* o = base + ww.slab[0] * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc0[r];
+    o = base + ww.slab[1] * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc1[r];
+    o = base + ww.slab[2] * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc2[r];
+}
+
 // Sum the per-chunk partial Gram sub-tiles in fp64.  One workgroup of 1024 threads owns 64
 // consecutive Gram entries (one 256-byte line per chunk): thread (e = t & 63, grp = t >> 6) adds
 // chunks grp, grp+16, ... in increasing order, then the 16 group sums are combined in fixed order
@@ -543,7 +637,11 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     ga.K = K; ga.chunk = pl.chunk;
     ga.gpart = static_cast<float*>(ws);
     double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.gpart_bytes);
-    if (ga.mask == 0x3FFu && gram_use_x3()) hipLaunchKernelGGL(gram128_partial_x3, dim3(pl.nchunk), dim3(256), 0, st, ga);
+    if (ga.mask == 0x3FFu && gram_use_x3()) {
+        const char* e = getenv("KCCOT_GRAM_WS");   // =0: the single-role x3 kernel (A/B)
+        if (e && atoi(e) == 0) hipLaunchKernelGGL(gram128_partial_x3, dim3(pl.nchunk), dim3(256), 0, st, ga);
+        else hipLaunchKernelGGL(gram128_partial_x3ws, dim3(pl.nchunk), dim3(512), 0, st, ga);
+    }
     else if (ga.mask == 0x3FFu) hipLaunchKernelGGL(gram128_partial<true>, dim3(pl.nchunk), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL(gram128_partial<false>, dim3(pl.nchunk), dim3(256), 0, st, ga);
     int rc = launch_status("gram128_partial");

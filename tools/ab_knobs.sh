@@ -15,7 +15,8 @@ PY
 }
 for rep in 1 2; do
 run default_$rep A=1 &&
+run ws0_$rep KCCOT_GRAM_WS=0 &&
+run wgs256_$rep KCCOT_GRAM_WGS=300 &&
 run wgs480_$rep KCCOT_GRAM_WGS=480 &&
-run wgs720_$rep KCCOT_GRAM_WGS=720 &&
 run f32_$rep KCCOT_GRAM_F32=1 || exit 1
 done
