@@ -383,28 +383,34 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
             rp[j] = (j < 4 ? ga.src1 : ga.src2) + (int64_t)r * ga.K;
         }
         const int wbase = r0 * XPITCH + c4 * 2;
-        float4 v[8];
+        // Two register sets = two stages (64 KB per CU) of HBM reads in flight: one stage ahead is
+        // not enough to cover the loaded-chip latency (Little: 6 TB/s / 256 CUs x ~2 us = 47 KB).
+        float4 va[8], vb[8];
+        auto fetch = [&](float4 (&v)[8], int st) {
+            const int64_t k = kbeg + (int64_t)st * XKT + c4;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kbeg + c4, kend, ok[j]);
-        for (int s = 0; s <= nstage; ++s) {
-            // stage s goes into buffer s&1 (the consumers read it during iteration s+1 of this loop)
-            if (s < nstage) {
-                unsigned char* zb = (s & 1) ? zsB : zsA;
+            for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], k, kend, ok[j] && st < nstage);
+        };
+        auto emit = [&](float4 (&v)[8], unsigned char* zb) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (ga.pair_diff) {
-                        v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
-                    }
-                    split3_store(zb, wbase + 16 * j * XPITCH, v[j]);
-                    split3_store(zb, wbase + (64 + 16 * j) * XPITCH, v[j + 4]);
+            for (int j = 0; j < 4; ++j) {
+                if (ga.pair_diff) {
+                    v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
                 }
-                const int64_t kn = kbeg + (int64_t)(s + 1) * XKT;
-                if (s + 1 < nstage) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kn + c4, kend, ok[j]);
-                }
+                split3_store(zb, wbase + 16 * j * XPITCH, v[j]);
+                split3_store(zb, wbase + (64 + 16 * j) * XPITCH, v[j + 4]);
             }
+        };
+        fetch(va, 0);
+        fetch(vb, 1);
+        // stage s goes into buffer s&1; the consumers read it one barrier later
+        for (int s = 0; s <= nstage; s += 2) {
+            if (s < nstage) { emit(va, zsA); fetch(va, s + 2); }
             __syncthreads();
+            if (s + 1 <= nstage) {
+                if (s + 1 < nstage) { emit(vb, zsB); fetch(vb, s + 3); }
+                __syncthreads();
+            }
         }
         return;
     }
