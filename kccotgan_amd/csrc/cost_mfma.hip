@@ -366,10 +366,16 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int64_t kbeg = (int64_t)blockIdx.x * ga.chunk;
-    const int64_t kend = (kbeg + ga.chunk < ga.K) ? kbeg + ga.chunk : ga.K;
-    if (kbeg >= kend) return;
-    const int nstage = (int)((kend - kbeg + XKT - 1) / XKT);
+    // K is cut into 64-wide stages dealt round-robin to the workgroups: stage s of workgroup i is
+    // global stage s*gridDim.x + i, so at any moment the resident workgroups read ADJACENT 256-byte
+    // pieces of every row (DRAM-page friendly) instead of pieces 2 KB apart.  Any partition of K
+    // gives valid partial sums.
+    const int64_t kend = ga.K;
+    const int total = (int)((ga.K + XKT - 1) / XKT);
+    const int nstage = ((int)blockIdx.x < total) ? (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    if (nstage == 0) return;
+    const int64_t kbeg = (int64_t)blockIdx.x * XKT;
+    const int64_t kstride = (int64_t)gridDim.x * XKT;
 
     if (wave < 4) {
         // ------------------------------------------------------------------ producers
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
         // not enough to cover the loaded-chip latency (Little: 6 TB/s / 256 CUs x ~2 us = 47 KB).
         float4 va[8], vb[8];
         auto fetch = [&](float4 (&v)[8], int st) {
-            const int64_t k = kbeg + (int64_t)st * XKT + c4;
+            const int64_t k = kbeg + (int64_t)st * kstride + c4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], k, kend, ok[j] && st < nstage);
         };
