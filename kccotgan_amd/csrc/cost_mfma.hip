@@ -366,16 +366,10 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // K is cut into 64-wide stages dealt round-robin to the workgroups: stage s of workgroup i is
-    // global stage s*gridDim.x + i, so at any moment the resident workgroups read ADJACENT 256-byte
-    // pieces of every row (DRAM-page friendly) instead of pieces 2 KB apart.  Any partition of K
-    // gives valid partial sums.
-    const int64_t kend = ga.K;
-    const int total = (int)((ga.K + XKT - 1) / XKT);
-    const int nstage = ((int)blockIdx.x < total) ? (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    if (nstage == 0) return;
-    const int64_t kbeg = (int64_t)blockIdx.x * XKT;
-    const int64_t kstride = (int64_t)gridDim.x * XKT;
+    const int64_t kbeg = (int64_t)blockIdx.x * ga.chunk;
+    const int64_t kend = (kbeg + ga.chunk < ga.K) ? kbeg + ga.chunk : ga.K;
+    if (kbeg >= kend) return;
+    const int nstage = (int)((kend - kbeg + XKT - 1) / XKT);
 
     if (wave < 4) {
         // ------------------------------------------------------------------ producers
@@ -389,34 +383,28 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
             rp[j] = (j < 4 ? ga.src1 : ga.src2) + (int64_t)r * ga.K;
         }
         const int wbase = r0 * XPITCH + c4 * 2;
-        // Two register sets = two stages (64 KB per CU) of HBM reads in flight: one stage ahead is
-        // not enough to cover the loaded-chip latency (Little: 6 TB/s / 256 CUs x ~2 us = 47 KB).
-        float4 va[8], vb[8];
-        auto fetch = [&](float4 (&v)[8], int st) {
-            const int64_t k = kbeg + (int64_t)st * kstride + c4;
+        float4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], k, kend, ok[j] && st < nstage);
-        };
-        auto emit = [&](float4 (&v)[8], unsigned char* zb) {
+        for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kbeg + c4, kend, ok[j]);
+        for (int s = 0; s <= nstage; ++s) {
+            // stage s goes into buffer s&1 (the consumers read it during iteration s+1 of this loop)
+            if (s < nstage) {
+                unsigned char* zb = (s & 1) ? zsB : zsA;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (ga.pair_diff) {
-                    v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
+                for (int j = 0; j < 4; ++j) {
+                    if (ga.pair_diff) {
+                        v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
+                    }
+                    split3_store(zb, wbase + 16 * j * XPITCH, v[j]);
+                    split3_store(zb, wbase + (64 + 16 * j) * XPITCH, v[j + 4]);
                 }
-                split3_store(zb, wbase + 16 * j * XPITCH, v[j]);
-                split3_store(zb, wbase + (64 + 16 * j) * XPITCH, v[j + 4]);
+                const int64_t kn = kbeg + (int64_t)(s + 1) * XKT;
+                if (s + 1 < nstage) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kn + c4, kend, ok[j]);
+                }
             }
-        };
-        fetch(va, 0);
-        fetch(vb, 1);
-        // stage s goes into buffer s&1; the consumers read it one barrier later
-        for (int s = 0; s <= nstage; s += 2) {
-            if (s < nstage) { emit(va, zsA); fetch(va, s + 2); }
             __syncthreads();
-            if (s + 1 <= nstage) {
-                if (s + 1 < nstage) { emit(vb, zsB); fetch(vb, s + 3); }
-                __syncthreads();
-            }
         }
         return;
     }
