@@ -134,6 +134,18 @@ int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const float* v_h
                            const float* gcost, float* dC_out,
                            void* ws, size_t ws_bytes, kccot_stream_t stream);
 
+/* The three solves of compute_sinkhorn_loss AND their combination in ONE launch each way
+ * (gan_utils.py:221-225): C3 = [xy, xx, yy] as [3,n,n]; loss_out = 2*cost3[0] - cost3[1] - cost3[2]
+ * is written by the last workgroup to finish.  `ticket` is one device int32 that must be ZERO on
+ * entry; the kernel leaves it zero.  Backward: gloss is ONE device float (dLoss/dloss). */
+int kccot_sinkhorn_divergence_fwd_f32(const float* C3, int n, float eps, int L, int Lmin, float thresh,
+                                      float* u_hist, float* v_hist, float* cost3_out, int32_t* nits_out,
+                                      float* loss_out, int32_t* ticket, void* ws, size_t ws_bytes,
+                                      kccot_stream_t stream);
+int kccot_sinkhorn_divergence_bwd_f32(const float* C3, const float* u_hist, const float* v_hist,
+                                      const int32_t* nits, int n, float eps, int L, const float* gloss,
+                                      float* dC3_out, void* ws, size_t ws_bytes, kccot_stream_t stream);
+
 /* Mixed Sinkhorn divergence (gan_utils.py:225): loss = 2*cost3[0] - cost3[1] - cost3[2] for
  * cost3 = [W(real,fake), W(real,real), W(fake,fake)], and its backward gcost3 = gloss*[2,-1,-1].
  * All arguments are device pointers (one launch each, no host round trip). */

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void cost_direct_partial(CostBatch cb, int64_t
 // finalize: one thread per output element
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cost_finalize(CostBatch cb, int nchunk, float sc, int T, int J) {
-    __shared__ float sh[CAUSAL_TILE * CAUSAL_PITCH], sm[CAUSAL_TILE * CAUSAL_PITCH];
+    __shared__ __attribute__((aligned(16))) float sh[CAUSAL_TILE * CAUSAL_PITCH];
+    __shared__ __attribute__((aligned(16))) float sm[CAUSAL_TILE * CAUSAL_PITCH];
     const int p = blockIdx.z;
     const CostProb& pr = cb.p[p];
     const int i0 = blockIdx.y * CAUSAL_TILE, j0 = blockIdx.x * CAUSAL_TILE;

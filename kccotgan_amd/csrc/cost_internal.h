@@ -42,7 +42,7 @@ struct CostPlan {
 // sh, sm: CAUSAL_TILE*CAUSAL_PITCH floats of LDS each.  Every thread of the block must call it.
 constexpr int CAUSAL_TILE = 16;
 constexpr int CAUSAL_KC = 256;
-constexpr int CAUSAL_PITCH = CAUSAL_KC + 1;
+constexpr int CAUSAL_PITCH = CAUSAL_KC + 4;   // 260: rows 16-byte aligned and 4 banks apart -> conflict-free ds_read_b128
 
 __device__ __forceinline__ float causal_tile16(const float* __restrict__ h, const float* __restrict__ M, int i0,
                                                int j0, int Bx, int By, int T, int J, float* sh, float* sm) {
@@ -63,8 +63,12 @@ __device__ __forceinline__ float causal_tile16(const float* __restrict__ h, cons
             sm[row * CAUSAL_PITCH + kk] = d;
         }
         __syncthreads();
-#pragma unroll 16
-        for (int kk = 0; kk < CAUSAL_KC; ++kk) tot = fmaf(sh[ti * CAUSAL_PITCH + kk], sm[tj * CAUSAL_PITCH + kk], tot);
+#pragma unroll 8
+        for (int kk = 0; kk < CAUSAL_KC; kk += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(&sh[ti * CAUSAL_PITCH + kk]);
+            const float4 b = *reinterpret_cast<const float4*>(&sm[tj * CAUSAL_PITCH + kk]);
+            tot = fmaf(a.x, b.x, tot); tot = fmaf(a.y, b.y, tot); tot = fmaf(a.z, b.z, tot); tot = fmaf(a.w, b.w, tot);
+        }
         __syncthreads();
     }
     return tot;

@@ -507,7 +507,8 @@ __device__ __forceinline__ double gram_at(const double* __restrict__ gsum, int s
 
 // One 16x16 output tile per block: distances from the summed Gram entries (fp64), scale, causal term.
 __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
-    __shared__ float sh[CAUSAL_TILE * CAUSAL_PITCH], sm[CAUSAL_TILE * CAUSAL_PITCH];
+    __shared__ __attribute__((aligned(16))) float sh[CAUSAL_TILE * CAUSAL_PITCH];
+    __shared__ __attribute__((aligned(16))) float sm[CAUSAL_TILE * CAUSAL_PITCH];
     const int p = blockIdx.z;
     const int i0 = blockIdx.y * CAUSAL_TILE, j0 = blockIdx.x * CAUSAL_TILE;
     const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);

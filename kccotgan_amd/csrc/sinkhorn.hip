@@ -84,6 +84,8 @@ struct SinkArgs {
     int32_t* nits_out;    // [nprob]
     float* pi_out;        // [nprob,n,n] or null
     unsigned long long* diag;   // diagnostic build only; null otherwise
+    float* loss_out;      // mixed divergence 2*cost[0]-cost[1]-cost[2] (nprob == 3), or null
+    int* ticket;          // arrival counter for loss_out: zero on entry, reset to zero by the last workgroup
 };
 
 // Load the EPT contiguous duals a thread needs (entries q*EPT .. q*EPT+EPT-1) from LDS.
@@ -241,6 +243,23 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
     if (t == 0) {
         a.cost_out[p] = cost;
         a.nits_out[p] = nits;
+        if (a.loss_out) {
+            // the last of the three workgroups to arrive combines the costs (gan_utils.py:225).
+            // Placement-independent hand-off (cdna_hip_programming.md G16, counter form): plain store ->
+            // agent-scope release -> relaxed ticket; the last arriver reads the costs with agent-scope
+            // (L1-bypassing) loads.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int tk = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk == (int)gridDim.x - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const float c0 = __hip_atomic_load(a.cost_out + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float c1 = __hip_atomic_load(a.cost_out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float c2 = __hip_atomic_load(a.cost_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.loss_out[0] = (2.0f * c0 - c1) - c2;
+                __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -269,10 +288,11 @@ struct SinkBwdArgs {
     const float* u_hist;
     const float* v_hist;
     const int32_t* nits;
-    const float* gcost;
+    const float* gcost;   // [nprob], or with div_weights: ONE upstream scalar dLoss/dloss
     float* dC;
     int n, L;
     float eps, inv_eps;
+    int div_weights;      // 1: gcost[p] = {2,-1,-1}[p] * gcost[0]   (d(2 xy - xx - yy), gan_utils.py:225)
 };
 
 template <int EPT, int LPR>
@@ -286,7 +306,8 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
     const int t = threadIdx.x, line = t / LPR, q = t % LPR;
     const bool active = line < n;
     const float* C = a.C + (int64_t)p * n * n;
-    const float k2 = a.inv_eps * LOG2E, g = a.gcost[p];
+    const float k2 = a.inv_eps * LOG2E;
+    const float g = a.div_weights ? (p == 0 ? 2.0f : -1.0f) * a.gcost[0] : a.gcost[p];
     const int nits = a.nits[p];
     const float* uh = a.u_hist + (int64_t)p * a.L * n;
     const float* vh = a.v_hist + (int64_t)p * a.L * n;
@@ -460,6 +481,11 @@ int launch_sinkhorn_bwd_gen(const float* C, const float* u_hist, const float* v_
 
 using namespace kccot;
 
+// set by the *_divergence_* entry points around their call into the base functions
+static thread_local float* g_div_loss = nullptr;
+static thread_local int* g_div_ticket = nullptr;
+static thread_local int g_div_weights = 0;
+
 extern "C" size_t kccot_sinkhorn_workspace_bytes(int nprob, int n) {
     if (nprob <= 0 || n <= SK_MAXN) return 0;   // the register-resident kernels need none
     return sinkhorn_gen_workspace_bytes(nprob, n);
@@ -500,7 +526,7 @@ extern "C" int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float ep
                                        pi_out, ws, ws_bytes, (hipStream_t)stream);
     SinkGeom g = sink_geom(n);
     SinkArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
-               nullptr};
+               nullptr, g_div_loss, g_div_ticket};
 #ifdef KCCOT_DIAG
     a.diag = static_cast<unsigned long long*>(ws);   // diagnostic build: ws carries the stamp buffer
 #endif
@@ -521,7 +547,7 @@ extern "C" int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const
         return launch_sinkhorn_bwd_gen(C, u_hist, v_hist, nits, nprob, n, eps, L, gcost, dC_out, ws, ws_bytes,
                                        (hipStream_t)stream);
     SinkGeom g = sink_geom(n);
-    SinkBwdArgs a{C, u_hist, v_hist, nits, gcost, dC_out, n, L, eps, (float)(1.0 / (double)eps)};
+    SinkBwdArgs a{C, u_hist, v_hist, nits, gcost, dC_out, n, L, eps, (float)(1.0 / (double)eps), g_div_weights};
     hipStream_t st = (hipStream_t)stream;
     KCCOT_SK_DISPATCH(sinkhorn_bwd_reg, a, g, nprob, st)
     return launch_status("sinkhorn_bwd_reg");
@@ -537,4 +563,37 @@ extern "C" int kccot_mixed_divergence_bwd_f32(const float* gloss, float* gcost3_
     if (!gloss || !gcost3_out) return fail(KCCOT_EINVAL, "mixed_divergence_bwd: null pointer");
     hipLaunchKernelGGL(mixed_divergence_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, gloss, gcost3_out);
     return launch_status("mixed_divergence_bwd");
+}
+
+// Mixed Sinkhorn divergence in one launch each way (compute_sinkhorn_loss, gan_utils.py:221-225):
+// the three solves of C3 = [xy, xx, yy] plus loss = 2 xy - xx - yy, combined by the last workgroup
+// to finish.  `ticket` is ONE device int that must be zero on entry (the kernel leaves it zero).
+extern "C" int kccot_sinkhorn_divergence_fwd_f32(const float* C3, int n, float eps, int L, int Lmin, float thresh,
+                                                 float* u_hist, float* v_hist, float* cost3_out, int32_t* nits_out,
+                                                 float* loss_out, int32_t* ticket, void* ws, size_t ws_bytes,
+                                                 kccot_stream_t stream) {
+    if (!loss_out || !ticket) return fail(KCCOT_EINVAL, "sinkhorn_divergence_fwd: null pointer");
+    if (n > SK_MAXN) {   // streaming solver: no in-kernel combine; fall back to the separate launch
+        int rc = kccot_sinkhorn_fwd_f32(C3, 3, n, eps, L, Lmin, thresh, KCCOT_STOP_COUNT, u_hist, v_hist, cost3_out, nits_out,
+                                        nullptr, ws, ws_bytes, stream);
+        if (rc) return rc;
+        return kccot_mixed_divergence_fwd_f32(cost3_out, loss_out, stream);
+    }
+    g_div_loss = loss_out; g_div_ticket = reinterpret_cast<int*>(ticket);
+    int rc = kccot_sinkhorn_fwd_f32(C3, 3, n, eps, L, Lmin, thresh, KCCOT_STOP_COUNT, u_hist, v_hist, cost3_out, nits_out,
+                                    nullptr, ws, ws_bytes, stream);
+    g_div_loss = nullptr; g_div_ticket = nullptr;
+    return rc;
+}
+
+// gloss: ONE device float dLoss/dloss; dC3_out = d loss / d C3 scaled by it.
+extern "C" int kccot_sinkhorn_divergence_bwd_f32(const float* C3, const float* u_hist, const float* v_hist,
+                                                 const int32_t* nits, int n, float eps, int L, const float* gloss,
+                                                 float* dC3_out, void* ws, size_t ws_bytes, kccot_stream_t stream) {
+    if (!gloss) return fail(KCCOT_EINVAL, "sinkhorn_divergence_bwd: null pointer");
+    if (n > SK_MAXN) return fail(KCCOT_EUNSUPPORTED, "sinkhorn_divergence_bwd: use mixed_divergence_bwd + sinkhorn_bwd for n > %d", SK_MAXN);
+    g_div_weights = 1;
+    int rc = kccot_sinkhorn_bwd_f32(C3, u_hist, v_hist, nits, 3, n, eps, L, gloss, dC3_out, ws, ws_bytes, stream);
+    g_div_weights = 0;
+    return rc;
 }

@@ -192,6 +192,61 @@ class _Sinkhorn(torch.autograd.Function):
         return dC, None, None, None, None, None
 
 
+_tickets = {}
+
+
+def _ticket(device):
+    """One zero-initialised device int per device: the arrival counter of the fused divergence kernel
+    (the kernel leaves it at zero)."""
+    t = _tickets.get(device)
+    if t is None:
+        t = torch.zeros((1,), dtype=torch.int32, device=device)
+        _tickets[device] = t
+    return t
+
+
+class _SinkhornDivergence(torch.autograd.Function):
+    """loss = 2 W(C3[0]) - W(C3[1]) - W(C3[2]) in one launch each way (gan_utils.py:221-225)."""
+
+    @staticmethod
+    def forward(ctx, C3, eps, L, Lmin, tag):
+        _, n, _ = C3.shape
+        C3 = C3.contiguous()
+        dev = C3.device
+        Lh = max(int(L), 1)
+        u_hist = _lib.empty((3, Lh, n), torch.float32, dev)
+        v_hist = _lib.empty((3, Lh, n), torch.float32, dev)
+        cost = _lib.empty((3,), torch.float32, dev)
+        nits = _lib.empty((3,), torch.int32, dev)
+        loss = _lib.empty((1,), torch.float32, dev)
+        ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(3, n), C3)
+        check(lib.kccot_sinkhorn_divergence_fwd_f32(ptr(C3), n, float(eps), int(L), int(Lmin), _THRESH, ptr(u_hist),
+                                                    ptr(v_hist), ptr(cost), ptr(nits), ptr(loss), ptr(_ticket(dev)),
+                                                    ws, wsb, stream_of(C3)), "sinkhorn_divergence_fwd")
+        last_info[tag] = nits
+        last_info[tag + "_costs"] = cost
+        ctx.save_for_backward(C3, u_hist, v_hist, nits)
+        ctx.eps, ctx.Lh = float(eps), Lh
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        C3, u_hist, v_hist, nits = ctx.saved_tensors
+        _, n, _ = C3.shape
+        g = g.reshape(1).contiguous().float()
+        dC = _lib.empty_like(C3)
+        ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(3, n), C3)
+        if n > 128:   # streaming solver: separate combine
+            gc = _lib.empty((3,), torch.float32, g.device)
+            check(lib.kccot_mixed_divergence_bwd_f32(ptr(g), ptr(gc), stream_of(g)), "mixed_divergence_bwd")
+            check(lib.kccot_sinkhorn_bwd_f32(ptr(C3), ptr(u_hist), ptr(v_hist), ptr(nits), 3, n, ctx.eps, ctx.Lh,
+                                             ptr(gc), ptr(dC), ws, wsb, stream_of(C3)), "sinkhorn_bwd")
+        else:
+            check(lib.kccot_sinkhorn_divergence_bwd_f32(ptr(C3), ptr(u_hist), ptr(v_hist), ptr(nits), n, ctx.eps, ctx.Lh,
+                                                        ptr(g), ptr(dC), ws, wsb, stream_of(C3)), "sinkhorn_divergence_bwd")
+        return dC, None, None, None, None
+
+
 class _MixedDivergence(torch.autograd.Function):
     """loss = 2*W_xy - W_xx - W_yy (gan_utils.py:225) as one launch each way."""
 
@@ -298,5 +353,4 @@ def compute_sinkhorn_loss(f_real, f_fake, scaling_coef, sinkhorn_eps, sinkhorn_l
     eps, L = (float(sinkhorn_eps), int(sinkhorn_l)) if honor_eps_l else (1.0, 100)
     real, fake = _flat2(f_real), _flat2(f_fake)
     C3 = _Cost3.apply(real, fake, _feat(h_fake), _feat(h_real), _feat(m_real), _feat(m_fake), float(scaling_coef))
-    w = _Sinkhorn.apply(C3, eps, L, _LMIN, _lib.STOP_COUNT, "compute_sinkhorn_loss")   # [xy, xx, yy]
-    return _MixedDivergence.apply(w)
+    return _SinkhornDivergence.apply(C3, eps, L, _LMIN, "compute_sinkhorn_loss")        # C3 = [xy, xx, yy]
