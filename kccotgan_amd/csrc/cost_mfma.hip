@@ -500,9 +500,10 @@ struct GramFin {
 };
 
 __device__ __forceinline__ double gram_at(const double* __restrict__ gsum, int s, int t) {
-    int a = s >> 5, b = t >> 5;
-    if (a > b) { int x = s; s = t; t = x; x = a; a = b; b = x; }
-    return gsum[sub_index(a, b) * 1024 + (s & 31) * 32 + (t & 31)];
+    // branch-free (selects): only sub-tiles on/above the diagonal are stored
+    const bool sw = (s >> 5) > (t >> 5);
+    const int s2 = sw ? t : s, t2 = sw ? s : t;
+    return gsum[sub_index(s2 >> 5, t2 >> 5) * 1024 + (s2 & 31) * 32 + (t2 & 31)];
 }
 
 // One 16x16 output tile per block: distances from the summed Gram entries (fp64), scale, causal term.
@@ -514,27 +515,27 @@ __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
     const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
     const bool ok = i < f.B1 && j < f.B2;
     const double* G = f.gsum;
-    double D = 0.0;
-    if (ok) {
-        if (f.mode == GRAM_LOSS3) {
-            const double dxx = (i == j) ? 0.0 : gram_at(G, i, i) + gram_at(G, j, j) - 2.0 * gram_at(G, i, j);
-            if (p == 1) {
-                D = dxx;
-            } else if (p == 0) {
-                D = dxx + gram_at(G, 64 + j, 64 + j) - 2.0 * (gram_at(G, i, 64 + j) - gram_at(G, j, 64 + j));
-            } else if (i != j) {
-                const double dee = gram_at(G, 64 + i, 64 + i) + gram_at(G, 64 + j, 64 + j)
-                                   - 2.0 * gram_at(G, 64 + i, 64 + j);
-                D = dxx + dee + 2.0 * (gram_at(G, i, 64 + i) - gram_at(G, i, 64 + j)
-                                       - gram_at(G, j, 64 + i) + gram_at(G, j, 64 + j));
-            }
-        } else if (f.mode == GRAM_XY) {
-            D = gram_at(G, i, i) + gram_at(G, 64 + j, 64 + j) - 2.0 * gram_at(G, i, 64 + j);
-        } else {  // GRAM_SAME: row i of x is stack row i (rows 64.. come from src2 = x + 64 rows)
-            D = (i == j) ? 0.0 : gram_at(G, i, i) + gram_at(G, j, j) - 2.0 * gram_at(G, i, j);
-        }
-        if (D < 0.0) D = 0.0;   // a squared distance; rounding of the Gram terms may leave -tiny
+    // all Gram entries are fetched up front (no control flow between the loads: one memory round trip)
+    const int ii = ok ? i : 0, jj = ok ? j : 0;
+    double D;
+    if (f.mode == GRAM_LOSS3) {
+        const double g_ii = gram_at(G, ii, ii), g_jj = gram_at(G, jj, jj), g_ij = gram_at(G, ii, jj);
+        const double e_ii = gram_at(G, 64 + ii, 64 + ii), e_jj = gram_at(G, 64 + jj, 64 + jj), e_ij = gram_at(G, 64 + ii, 64 + jj);
+        const double x_ii = gram_at(G, ii, 64 + ii), x_jj = gram_at(G, jj, 64 + jj);
+        const double x_ij = gram_at(G, ii, 64 + jj), x_ji = gram_at(G, jj, 64 + ii);
+        const bool diag = ii == jj;
+        const double dxx = diag ? 0.0 : g_ii + g_jj - 2.0 * g_ij;
+        const double dxy = dxx + e_jj - 2.0 * (x_ij - x_jj);
+        const double dee = e_ii + e_jj - 2.0 * e_ij;
+        const double dyy = diag ? 0.0 : dxx + dee + 2.0 * (x_ii - x_ij - x_ji + x_jj);
+        D = (p == 1) ? dxx : (p == 0 ? dxy : dyy);
+    } else if (f.mode == GRAM_XY) {
+        D = gram_at(G, ii, ii) + gram_at(G, 64 + jj, 64 + jj) - 2.0 * gram_at(G, ii, 64 + jj);
+    } else {  // GRAM_SAME: row i of x is stack row i (rows 64.. come from src2 = x + 64 rows)
+        const double g_ii = gram_at(G, ii, ii), g_jj = gram_at(G, jj, jj), g_ij = gram_at(G, ii, jj);
+        D = (ii == jj) ? 0.0 : g_ii + g_jj - 2.0 * g_ij;
     }
+    if (D < 0.0) D = 0.0;   // a squared distance; rounding of the Gram terms may leave -tiny
     float c = (float)D * f.sc;
     if (f.h[p]) c += causal_tile16(f.h[p], f.M[p], i0, j0, f.B1, f.B2, f.T, f.J, sh, sm) * f.sc;
     if (p == 0 && f.h2) c += causal_tile16(f.h2, f.M2, i0, j0, f.B1, f.B2, f.T, f.J, sh, sm) * f.sc;
