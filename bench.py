@@ -35,11 +35,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 
 
-def make_inputs(B, seed, device):
+def make_inputs(B, seed, device, regime="near"):
     import cases
     shape_name = "cfg2"
     assert cases.SHAPES[shape_name][0] == SHAPE["B"]
-    inp = cases.gen_inputs(shape_name, seed, "near")
+    inp = cases.gen_inputs(shape_name, seed, regime)
     if B != SHAPE["B"]:
         inp = {k: v[:B] for k, v in inp.items()}
     return inp, {k: torch.from_numpy(v).to(device) for k, v in inp.items()}
@@ -139,6 +139,11 @@ def main():
             dist.init_process_group(backend)
 
     from kccotgan_amd import gan_utils as G
+    # The headline is timed with the Sinkhorn solver's exact periodic-state shortcut DISABLED, so that all
+    # 3 x 100 iterations (and the full reverse sweep) are executed whatever the data: `value` then
+    # does not depend on how quickly the synthetic batch happens to reach its fp32 fixed point.  The
+    # shipped default (shortcut on, bit-identical results) is timed separately below.
+    os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
     inp, t = make_inputs(SHAPE["B"], 0, dev)
     for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
         t[k].requires_grad_(True)
@@ -171,9 +176,10 @@ def main():
     ms = el / args.steps * 1e3
     if world > 1:
         from kccotgan_amd import dist as kd
-        nits = kd.last_info["nits"].tolist()
+        nits, nexec = kd.last_info["nits"].tolist(), kd.last_info["nits_executed"].tolist()
     else:
         nits = G.last_info["compute_sinkhorn_loss"].tolist()
+        nexec = G.last_info["compute_sinkhorn_loss_executed"].tolist()
 
     out = {
         "metric": "sinkhorn_loss_evals_per_sec", "value": args.steps / el, "unit": "loss-evals/s (fwd+bwd)",
@@ -182,8 +188,30 @@ def main():
         "config": {"workload": "BASELINE configs[1]: Moving-MNIST shape B=64,T=30,64x64x1, J=8, 100 Sinkhorn iters, "
                                "compute_sinkhorn_loss fwd+bwd", "global_batch": SHAPE["B"],
                    "parallelism": "single GPU" if world == 1 else "batch-sharded x%d, all-gather, replicated Sinkhorn" % world,
-                   "sinkhorn_iters_executed": nits, "loss": float(loss)},
+                   "sinkhorn_iters": nits, "sinkhorn_iters_executed": nexec, "sinkhorn_exact_shortcut": "off",
+                   "loss": float(loss)},
     }
+    if rank == 0 and world == 1:
+        # the shipped default: exact shortcut on.  Same outputs bit for bit (tests/test_gpu_parity.py::
+        # test_sinkhorn_periodic_state_shortcut_is_bit_exact); how much it saves depends on the data.
+        os.environ["KCCOT_SK_NO_SHORTCUT"] = "0"
+        extra = {}
+        for regime, seed in (("near", 0), ("far", 1)):
+            _, tr = make_inputs(SHAPE["B"], seed, dev, regime)
+            for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
+                tr[k].requires_grad_(True)
+            for _ in range(args.warmup):
+                l2, _g = loss_step(G, tr)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                l2, _g = loss_step(G, tr)
+            torch.cuda.synchronize()
+            extra[regime] = {"ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3, "loss": float(l2),
+                             "sinkhorn_iters": G.last_info["compute_sinkhorn_loss"].tolist(),
+                             "sinkhorn_iters_executed": G.last_info["compute_sinkhorn_loss_executed"].tolist()}
+        out["with_exact_shortcut"] = extra
+        os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
     if rank == 0 and world == 1:
         kt, K = time_cost_kernel(t)
         B, T, J = SHAPE["B"], SHAPE["T"], SHAPE["J"]

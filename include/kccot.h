@@ -116,7 +116,10 @@ int kccot_pairwise_cost_bwd_f32(const float* g, const float* x, const float* y, 
  *     u += eps*(log(1/n) - LSE_j((-C+u+v^T)/eps));  v += eps*(log(1/n) - LSE_i((-C+u+v^T)/eps))
  *     err = sum|u - u_prev|; stop per stop_mode once err < thresh
  *   cost = sum(exp((-C+u+v^T)/eps) * C)
- * C is [nprob,n,n].  cost_out [nprob], nits_out [nprob] (executed iterations, device int32).
+ * C is [nprob,n,n].  cost_out [nprob]; nits_out is device int32 [2*nprob]: nits_out[p] = the
+ * iteration count of the reference's loop (what its `actual_nits` would be), nits_out[nprob+p] = the
+ * iterations the kernel actually executed -- fewer when the fp32 state became bit-for-bit periodic
+ * and the remaining iterations were skipped EXACTLY (KCCOT_SK_NO_SHORTCUT=1 disables that).
  * u_hist / v_hist [nprob,L,n] receive u and v after every executed iteration (needed by the
  * backward; pass NULL for a forward-only evaluation).  pi_out [nprob,n,n] optional.
  * ------------------------------------------------------------------------------------------- */

@@ -86,6 +86,7 @@ struct SinkArgs {
     unsigned long long* diag;   // diagnostic build only; null otherwise
     float* loss_out;      // mixed divergence 2*cost[0]-cost[1]-cost[2] (nprob == 3), or null
     int* ticket;          // arrival counter for loss_out: zero on entry, reset to zero by the last workgroup
+    int shortcut;         // 1: exact periodic-state shortcut enabled (see sinkhorn_fwd_reg)
 };
 
 // Load the EPT contiguous duals a thread needs (entries q*EPT .. q*EPT+EPT-1) from LDS.
@@ -190,6 +191,24 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
     const float lw2 = __builtin_amdgcn_logf(1.0f / (float)n);   // log2(mu) = log2(nu), gan_utils.py:138-139
     // stop rule in log2 units: sum|u-u_prev| = sum|U-U_prev| * eps*ln2
     const float err_scale = a.eps * LN2;
+
+    // EXACT shortcut.  One iteration is a deterministic function of the state (u,v).  As soon as the
+    // state after iteration k equals, bit for bit, the state after iteration k-p (p <= 4) the
+    // sequence is periodic from there on, and the state after any later iteration K is the stored
+    // state k - p + ((K-k) mod p): nothing is approximated, the loop is merely not re-executed.
+    // (Sharp problems -- costs of O(1e3) against eps = 1, the GAN regime -- reach an fp32 fixed point
+    // within a handful of iterations.)  The kernel jumps to one iteration before the first point at
+    // which the reference's stop rule could fire (or before L), fills the history the backward
+    // needs, and resumes the ordinary loop, so the stop logic and the final iterate are computed
+    // by the same code as without the shortcut.  nits_out[p] is the reference-equivalent iteration
+    // count; nits_out[nprob + p] the number of iterations actually executed.
+    __shared__ float ring_u[4][SK_MAXN], ring_v[4][SK_MAXN];
+    __shared__ int mis[2];
+    if (t < 2) mis[t] = 0;
+    __syncthreads();
+    bool detect = a.shortcut != 0;
+    int computed = 0;
+
     int nits = 0;
     float ui = 0.f, vj = 0.f;   // this line's duals (every lane of the line holds them)
     for (int it = 0; it < a.L; ++it) {
@@ -199,9 +218,16 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
         KCCOT_STAMP(1);
         const float du = (active && q == 0) ? fabsf(un - ui) : 0.f;
         ui = un;
+        int bits = 0;
         if (active && q == 0) {
             u_s[line] = un;
             if (a.u_hist) a.u_hist[((int64_t)p * a.L + it) * n + line] = un;
+            if (detect) {
+#pragma unroll
+                for (int pp = 1; pp <= 4; ++pp)
+                    if (it >= pp && __float_as_uint(un) != __float_as_uint(ring_u[(it - pp) & 3][line])) bits |= 1 << pp;
+                ring_u[it & 3][line] = un;
+            }
         }
         KCCOT_STAMP(2);
         __syncthreads();
@@ -212,17 +238,61 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
         if (active && q == 0) {
             v_s[line] = vn;
             if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + line] = vn;
+            if (detect) {
+#pragma unroll
+                for (int pp = 1; pp <= 4; ++pp)
+                    if (it >= pp && __float_as_uint(vn) != __float_as_uint(ring_v[(it - pp) & 3][line])) bits |= 1 << pp;
+                ring_v[it & 3][line] = vn;
+                if (bits) atomicOr(&mis[it & 1], bits);
+            }
         }
         KCCOT_STAMP(5);
         __syncthreads();
         KCCOT_STAMP(6);
         nits = it + 1;
+        ++computed;
         // gan_utils.py:157-160 (count-based) / :115-117 (index-based).  err is only needed once
         // the stop rule can fire, and never on the last iteration.
         const bool reached = (a.stop_mode == KCCOT_STOP_INDEX) ? (it >= a.Lmin) : (nits >= a.Lmin);
         if (reached && it + 1 < a.L) {
             const float err = block_sum(du, red) * err_scale;
             if (a.thresh > err) break;
+        }
+        if (detect) {
+            const int m = mis[it & 1];
+            if (t == 0) mis[(it + 1) & 1] = 0;
+            int per = 0;
+#pragma unroll
+            for (int pp = 4; pp >= 1; --pp)
+                if (it >= pp && !((m >> pp) & 1)) per = pp;          // smallest matching period
+            if (per) {
+                detect = false;
+                // first iteration count at which the reference could leave its loop early
+                int first_stop = (a.stop_mode == KCCOT_STOP_INDEX) ? a.Lmin + 1 : a.Lmin;
+                if (first_stop < 1) first_stop = 1;
+                const int K1 = (a.L < first_stop ? a.L : first_stop) - 1;   // resume so that iteration K1+1 is real
+                if (K1 > nits) {
+                    // S_k for k > nits is S_{src(k)}, src(k) = nits if (k-nits) % per == 0 else nits - per + (k-nits) % per;
+                    // S_k lives in ring slot (k-1) & 3
+                    if (a.u_hist) {
+                        for (int e = t; e < (K1 - nits) * n; e += blockDim.x) {
+                            const int k = nits + 1 + e / n, i = e % n, r = (k - nits) % per;
+                            const int slot = ((r == 0 ? nits : nits - per + r) - 1) & 3;
+                            a.u_hist[((int64_t)p * a.L + (k - 1)) * n + i] = ring_u[slot][i];
+                            a.v_hist[((int64_t)p * a.L + (k - 1)) * n + i] = ring_v[slot][i];
+                        }
+                    }
+                    const int r = (K1 - nits) % per;
+                    const int slot = ((r == 0 ? nits : nits - per + r) - 1) & 3;
+                    __syncthreads();
+                    if (t < n) { u_s[t] = ring_u[slot][t]; v_s[t] = ring_v[slot][t]; }
+                    __syncthreads();
+                    ui = u_s[active ? line : 0];
+                    vj = v_s[active ? line : 0];
+                    nits = K1;
+                    it = K1 - 1;
+                }
+            }
         }
     }
 
@@ -243,6 +313,7 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
     if (t == 0) {
         a.cost_out[p] = cost;
         a.nits_out[p] = nits;
+        a.nits_out[gridDim.x + p] = computed;
         if (a.loss_out) {
             // the last of the three workgroups to arrive combines the costs (gan_utils.py:225).
             // Placement-independent hand-off (cdna_hip_programming.md G16, counter form): plain store ->
@@ -293,6 +364,7 @@ struct SinkBwdArgs {
     int n, L;
     float eps, inv_eps;
     int div_weights;      // 1: gcost[p] = {2,-1,-1}[p] * gcost[0]   (d(2 xy - xx - yy), gan_utils.py:225)
+    int shortcut;         // 1: leave the sweep once the carried gradient is exactly zero
 };
 
 template <int EPT, int LPR>
@@ -302,11 +374,13 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float V[2][PADN];
     __shared__ __attribute__((aligned(16))) float gu[PADN];
     __shared__ __attribute__((aligned(16))) float gv[PADN];
+    __shared__ int nz[2];
     const int p = blockIdx.x, n = a.n;
     const int t = threadIdx.x, line = t / LPR, q = t % LPR;
     const bool active = line < n;
     const float* C = a.C + (int64_t)p * n * n;
     const float k2 = a.inv_eps * LOG2E;
+    if (t < 2) nz[t] = 0;
     const float g = a.div_weights ? (p == 0 ? 2.0f : -1.0f) * a.gcost[0] : a.gcost[p];
     const int nits = a.nits[p];
     const float* uh = a.u_hist + (int64_t)p * a.L * n;
@@ -408,9 +482,18 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
                 r += w;
             }
             r = seg_sum<LPR>(r);
-            if (active && q == 0) gv[line] = -r;
+            if (active && q == 0) {
+                gv[line] = -r;
+                if (r != 0.f) atomicOr(&nz[it & 1], 1);
+            }
         }
         __syncthreads();
+        // EXACT early exit: the only state carried to the older iterations is gv (gu restarts from 0).
+        // If every gv is +-0 then every further increment Q*gv, P*gu is exactly 0 and the rest of the
+        // sweep cannot change dC by a single bit.
+        const int any = nz[it & 1];
+        if (t == 0) nz[(it + 1) & 1] = 0;
+        if (a.shortcut && !any) break;
     }
 
     // dC = row-layout part + (column-layout part)^T
@@ -481,6 +564,11 @@ int launch_sinkhorn_bwd_gen(const float* C, const float* u_hist, const float* v_
 
 using namespace kccot;
 
+static int sink_shortcut_enabled() {
+    const char* e = getenv("KCCOT_SK_NO_SHORTCUT");   // =1: always execute every iteration (A/B, bitwise-equality tests)
+    return !(e && atoi(e) == 1);
+}
+
 // set by the *_divergence_* entry points around their call into the base functions
 static thread_local float* g_div_loss = nullptr;
 static thread_local int* g_div_ticket = nullptr;
@@ -526,7 +614,7 @@ extern "C" int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float ep
                                        pi_out, ws, ws_bytes, (hipStream_t)stream);
     SinkGeom g = sink_geom(n);
     SinkArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
-               nullptr, g_div_loss, g_div_ticket};
+               nullptr, g_div_loss, g_div_ticket, sink_shortcut_enabled()};
 #ifdef KCCOT_DIAG
     a.diag = static_cast<unsigned long long*>(ws);   // diagnostic build: ws carries the stamp buffer
 #endif
@@ -547,7 +635,8 @@ extern "C" int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const
         return launch_sinkhorn_bwd_gen(C, u_hist, v_hist, nits, nprob, n, eps, L, gcost, dC_out, ws, ws_bytes,
                                        (hipStream_t)stream);
     SinkGeom g = sink_geom(n);
-    SinkBwdArgs a{C, u_hist, v_hist, nits, gcost, dC_out, n, L, eps, (float)(1.0 / (double)eps), g_div_weights};
+    SinkBwdArgs a{C, u_hist, v_hist, nits, gcost, dC_out, n, L, eps, (float)(1.0 / (double)eps), g_div_weights,
+                  sink_shortcut_enabled()};
     hipStream_t st = (hipStream_t)stream;
     KCCOT_SK_DISPATCH(sinkhorn_bwd_reg, a, g, nprob, st)
     return launch_status("sinkhorn_bwd_reg");

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(SG_THREADS) void sinkhorn_fwd_gen(SinkGenArgs a) {
         }
     }
     const float cost = block_sum(part, red);
-    if (t == 0) { a.cost_out[p] = cost; a.nits_out[p] = nits; }
+    if (t == 0) { a.cost_out[p] = cost; a.nits_out[p] = nits; a.nits_out[gridDim.x + p] = nits; }
 }
 
 struct SinkGenBwdArgs {

@@ -57,7 +57,7 @@ class HipOps:
         u_hist = _lib.empty((nprob, Lh, n), torch.float32, dev)
         v_hist = _lib.empty((nprob, Lh, n), torch.float32, dev)
         cost = _lib.empty((nprob,), torch.float32, dev)
-        nits = _lib.empty((nprob,), torch.int32, dev)
+        nits = _lib.empty((2 * nprob,), torch.int32, dev)
         ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(nprob, n), C3)
         check(lib.kccot_sinkhorn_fwd_f32(ptr(C3), nprob, n, float(eps), int(L), _LMIN, _THRESH, _lib.STOP_COUNT,
                                          ptr(u_hist), ptr(v_hist), ptr(cost), ptr(nits), None, ws, wsb,
@@ -143,7 +143,7 @@ class _ShardedLoss(torch.autograd.Function):
         C3 = all_gather_cat(blk.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()  # [3,B,B]
         cost3, saved = ops.sinkhorn3_fwd(C3, eps, L)
         if ops is HipOps:
-            last_info["nits"] = saved[3]
+            last_info["nits"], last_info["nits_executed"] = saved[3][:3], saved[3][3:]
         ctx.saved_state = (saved, real, fake, h_fake, h_real, m_real, m_fake)
         ctx.cfg = (sc, rank * Bl, Bl, ops)
         return (2.0 * cost3[0] - cost3[1]) - cost3[2]           # gan_utils.py:225

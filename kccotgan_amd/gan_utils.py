@@ -169,12 +169,12 @@ class _Sinkhorn(torch.autograd.Function):
         u_hist = _lib.empty((nprob, Lh, n), torch.float32, dev) if keep else None
         v_hist = _lib.empty((nprob, Lh, n), torch.float32, dev) if keep else None
         cost = _lib.empty((nprob,), torch.float32, dev)
-        nits = _lib.empty((nprob,), torch.int32, dev)
+        nits = _lib.empty((2 * nprob,), torch.int32, dev)   # [reference-equivalent counts | iterations executed]
         ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(nprob, n), C)
         check(lib.kccot_sinkhorn_fwd_f32(ptr(C), nprob, n, float(eps), int(L), int(Lmin), _THRESH, stop_mode,
                                          ptr(u_hist), ptr(v_hist), ptr(cost), ptr(nits), None, ws, wsb,
                                          stream_of(C)), "sinkhorn_fwd")
-        last_info[tag] = nits
+        last_info[tag], last_info[tag + "_executed"] = nits[:nprob], nits[nprob:]
         if keep:
             ctx.save_for_backward(C, u_hist, v_hist, nits)
         ctx.eps, ctx.Lh = float(eps), Lh
@@ -217,13 +217,13 @@ class _SinkhornDivergence(torch.autograd.Function):
         u_hist = _lib.empty((3, Lh, n), torch.float32, dev)
         v_hist = _lib.empty((3, Lh, n), torch.float32, dev)
         cost = _lib.empty((3,), torch.float32, dev)
-        nits = _lib.empty((3,), torch.int32, dev)
+        nits = _lib.empty((6,), torch.int32, dev)           # [reference-equivalent counts | iterations executed]
         loss = _lib.empty((1,), torch.float32, dev)
         ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(3, n), C3)
         check(lib.kccot_sinkhorn_divergence_fwd_f32(ptr(C3), n, float(eps), int(L), int(Lmin), _THRESH, ptr(u_hist),
                                                     ptr(v_hist), ptr(cost), ptr(nits), ptr(loss), ptr(_ticket(dev)),
                                                     ws, wsb, stream_of(C3)), "sinkhorn_divergence_fwd")
-        last_info[tag] = nits
+        last_info[tag], last_info[tag + "_executed"] = nits[:3], nits[3:]
         last_info[tag + "_costs"] = cost
         ctx.save_for_backward(C3, u_hist, v_hist, nits)
         ctx.eps, ctx.Lh = float(eps), Lh

@@ -181,7 +181,7 @@ def test_sinkhorn_kats(G, L):
     Cn = np.random.default_rng(0).random((n, n), dtype=np.float32) * 3
     C = torch.from_numpy(Cn).to(DEV).reshape(1, n, n)
     cost = torch.empty(1, device=DEV)
-    nits = torch.empty(1, dtype=torch.int32, device=DEV)
+    nits = torch.empty(2, dtype=torch.int32, device=DEV)
     pi = torch.empty(1, n, n, device=DEV)
     rc = lib.kccot_sinkhorn_fwd_f32(ptr(C), 1, n, 0.7, 13, 100, 1e-2, 0, None, None, ptr(cost), ptr(nits), ptr(pi),
                                     None, 0, None)
@@ -197,6 +197,81 @@ def test_sinkhorn_kats(G, L):
         got = G._Sinkhorn.apply(torch.from_numpy(Cn).to(DEV), 0.5, 37, 100, L.STOP_COUNT, "kat").cpu().numpy()
         for p in range(3):
             assert rel(got[p], o.sinkhorn_from_cost(Cn[p], 0.5, 37)[0]) < 2e-5, (n, p)
+
+
+def _raw_sinkhorn(L, C, eps, Lc, Lmin, mode, shortcut):
+    """kccot_sinkhorn_fwd_f32 + _bwd_f32 through the C ABI; every output, for bitwise comparison."""
+    lib, ptr = L.lib, L.ptr
+    nprob, n, _ = C.shape
+    old = os.environ.get("KCCOT_SK_NO_SHORTCUT")
+    os.environ["KCCOT_SK_NO_SHORTCUT"] = "0" if shortcut else "1"
+    try:
+        uh = torch.full((nprob, Lc, n), float("nan"), device=DEV)
+        vh = torch.full((nprob, Lc, n), float("nan"), device=DEV)
+        cost = torch.empty(nprob, device=DEV)
+        nits = torch.zeros(2 * nprob, dtype=torch.int32, device=DEV)
+        pi = torch.empty_like(C)
+        dC = torch.empty_like(C)
+        gc = torch.tensor([2.0, -1.0, -1.0][:nprob], device=DEV)
+        wsb = lib.kccot_sinkhorn_workspace_bytes(nprob, n)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+        assert lib.kccot_sinkhorn_fwd_f32(ptr(C), nprob, n, eps, Lc, Lmin, 1e-2, mode, ptr(uh), ptr(vh), ptr(cost),
+                                          ptr(nits), ptr(pi), ptr(ws), wsb, None) == 0
+        assert lib.kccot_sinkhorn_bwd_f32(ptr(C), ptr(uh), ptr(vh), ptr(nits), nprob, n, eps, Lc, ptr(gc), ptr(dC),
+                                          ptr(ws), wsb, None) == 0
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            del os.environ["KCCOT_SK_NO_SHORTCUT"]
+        else:
+            os.environ["KCCOT_SK_NO_SHORTCUT"] = old
+    nit = nits.cpu().numpy()
+    out = dict(cost=cost.cpu().numpy(), pi=pi.cpu().numpy(), dC=dC.cpu().numpy(), nits=nit[:nprob], executed=nit[nprob:])
+    # only the executed-or-filled part of the history is defined: rows [0, nits)
+    out["u"] = [uh[p, :nit[p]].cpu().numpy() for p in range(nprob)]
+    out["v"] = [vh[p, :nit[p]].cpu().numpy() for p in range(nprob)]
+    return out
+
+
+def _same_bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_sinkhorn_periodic_state_shortcut_is_bit_exact(G, L):
+    """The forward skips iterations once the fp32 state (u, v) repeats bit for bit with period <= 4,
+    and the reverse sweep stops once the carried gradient is exactly zero (sinkhorn.hip).  Both claim
+    to be EXACT: every output -- cost, plan, iteration count, the full dual history, dC -- must be
+    bit-identical to a run that executes every iteration (KCCOT_SK_NO_SHORTCUT=1)."""
+    probs = {}
+    for name, (shape, seed, regime) in dict(near=("cfg2", 0, "near"), far=("cfg2", 1, "far"), small=SMALL[0]).items():
+        g, inp, t = load(shape, seed, regime)
+        probs[name] = G._Cost3.apply(G._flat2(t["real"]), G._flat2(t["fake"]), G._feat(t["h_fake"]),
+                                     G._feat(t["h_real"]), G._feat(t["m_real"]), G._feat(t["m_fake"]),
+                                     float(cases.SC)).detach().contiguous()
+    rng = np.random.default_rng(7)
+    for n, scale in ((64, 2000.0), (64, 30.0), (33, 500.0), (100, 3000.0), (128, 800.0), (7, 100.0)):
+        probs["rand_n%d_s%g" % (n, scale)] = torch.from_numpy(
+            (rng.random((3, n, n), dtype=np.float32) * np.float32(scale))).to(DEV)
+    x, y, h, M = (torch.from_numpy(a).to(DEV) for a in cases.gen_line_inputs())     # stops at 198 of 300 (quirk 2)
+    probs["line32"] = G.modified_cost(x, y, h, M, 100.0).detach().reshape(1, x.shape[0], y.shape[0]).contiguous()
+    skipped_somewhere = False
+    for name, C in probs.items():
+        for eps, Lc, Lmin, mode in ((1.0, 100, 100, L.STOP_COUNT), (0.8, 50, 20, L.STOP_INDEX),
+                                    (1.0, 300, 100, L.STOP_COUNT), (1.0, 7, 100, L.STOP_COUNT),
+                                    (0.5, 40, 3, L.STOP_COUNT)):
+            a = _raw_sinkhorn(L, C, eps, Lc, Lmin, mode, shortcut=True)
+            b = _raw_sinkhorn(L, C, eps, Lc, Lmin, mode, shortcut=False)
+            tag = (name, eps, Lc, Lmin, mode)
+            assert np.array_equal(a["nits"], b["nits"]), tag
+            assert np.array_equal(b["executed"], b["nits"]), tag
+            assert (a["executed"] <= a["nits"]).all(), tag
+            skipped_somewhere |= bool((a["executed"] < a["nits"]).any())
+            for k in ("cost", "pi", "dC"):
+                assert _same_bits(a[k], b[k]), (tag, k)
+            for p in range(C.shape[0]):
+                assert _same_bits(a["u"][p], b["u"][p]) and _same_bits(a["v"][p], b["v"][p]), (tag, p)
+    assert skipped_somewhere      # the test must exercise the jump, not only the fall-through
 
 
 def test_sinkhorn_large_n_streaming_path(G, L):
@@ -319,7 +394,7 @@ def test_full_size_properties(G, L):
     # plan is a coupling: feed the golden cost matrix, check both marginals and the cost
     from kccotgan_amd._lib import lib, ptr
     C = torch.from_numpy(g["C_xy"]).to(DEV).reshape(1, B, B).contiguous()
-    cost = torch.empty(1, device=DEV); nits = torch.empty(1, dtype=torch.int32, device=DEV); pi = torch.empty(1, B, B, device=DEV)
+    cost = torch.empty(1, device=DEV); nits = torch.empty(2, dtype=torch.int32, device=DEV); pi = torch.empty(1, B, B, device=DEV)
     assert lib.kccot_sinkhorn_fwd_f32(ptr(C), 1, B, 1.0, 100, 100, 1e-2, 0, None, None, ptr(cost), ptr(nits), ptr(pi),
                                       None, 0, None) == 0
     torch.cuda.synchronize()

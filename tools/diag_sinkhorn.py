@@ -13,7 +13,7 @@ g = np.load(os.path.join(ROOT, "tests", "golden", "cfg2_s0_near.npz"))
 C = torch.from_numpy(np.stack([g["C_xy"], g["C_xx"], g["C_yy"]])).cuda()[:, :n, :n].contiguous()
 L = 100
 uh = torch.empty(3, L, n, device="cuda"); vh = torch.empty(3, L, n, device="cuda")
-cost = torch.empty(3, device="cuda"); nits = torch.empty(3, dtype=torch.int32, device="cuda")
+cost = torch.empty(3, device="cuda"); nits = torch.empty(6, dtype=torch.int32, device="cuda")
 diag = torch.zeros(3 * 16 * 16, dtype=torch.int64, device="cuda")
 for rep in range(3):
     rc = lib.kccot_sinkhorn_fwd_f32(C.data_ptr(), 3, n, 1.0, L, 100, 1e-2, 0, uh.data_ptr(), vh.data_ptr(), cost.data_ptr(),
