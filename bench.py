@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: one step = one compute_sinkhorn_loss evaluation, forward + backward
 (gradients w.r.t. fake, h_fake, h_real, m_real, m_fake -- what the reference's generator step
-differentiates, kernel_train.py:287-289), on synthetic video already resident in HBM.
+differentiates, kernel_train.py:287-289), on synthetic video already resident in HBM.  At N=1 the
+step is a hipGraph replay of the eight kernels (kccotgan_amd/graph.py; KCCOT_BENCH_EAGER=1 times
+eager launches instead, also reported as `eager_launches_ms_per_step`).
 
 Workload = BASELINE.json configs[1]: Moving-MNIST shape [B=64, H=64, T=30, W=64, C=1], J=8,
 scaling_coef=1/15, epsilon=1, 100 Sinkhorn iterations (the as-called behaviour of the
@@ -148,12 +150,21 @@ def main():
     for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
         t[k].requires_grad_(True)
 
+    mode = "eager launches"
     if world > 1:
         from kccotgan_amd import dist as kd
         shard = kd.shard_batch(t, rank, world)
         step = lambda: kd.sharded_loss_step(shard, SC)
-    else:
+    elif os.environ.get("KCCOT_BENCH_EAGER") == "1":
         step = lambda: loss_step(G, t)
+    else:
+        # the step as a training loop would run it: forward + backward captured once into a hipGraph
+        # (kccotgan_amd/graph.py) and replayed -- the same eight kernels with the same arguments, one
+        # hipGraphLaunch instead of eight launches issued from Python
+        from kccotgan_amd.graph import GraphedLossStep
+        graphed = GraphedLossStep(t, SC)
+        step = lambda: graphed()
+        mode = "hipGraph replay of forward+backward"
 
     def barrier():
         torch.cuda.synchronize()
@@ -177,9 +188,11 @@ def main():
     if world > 1:
         from kccotgan_amd import dist as kd
         nits, nexec = kd.last_info["nits"].tolist(), kd.last_info["nits_executed"].tolist()
-    else:
+    elif mode == "eager launches":
         nits = G.last_info["compute_sinkhorn_loss"].tolist()
         nexec = G.last_info["compute_sinkhorn_loss_executed"].tolist()
+    else:
+        nits, nexec = graphed.nits.tolist(), graphed.nits_executed.tolist()
 
     out = {
         "metric": "sinkhorn_loss_evals_per_sec", "value": args.steps / el, "unit": "loss-evals/s (fwd+bwd)",
@@ -189,29 +202,37 @@ def main():
                                "compute_sinkhorn_loss fwd+bwd", "global_batch": SHAPE["B"],
                    "parallelism": "single GPU" if world == 1 else "batch-sharded x%d, all-gather, replicated Sinkhorn" % world,
                    "sinkhorn_iters": nits, "sinkhorn_iters_executed": nexec, "sinkhorn_exact_shortcut": "off",
-                   "loss": float(loss)},
+                   "launch": mode, "loss": float(loss)},
     }
     if rank == 0 and world == 1:
         # the shipped default: exact shortcut on.  Same outputs bit for bit (tests/test_gpu_parity.py::
         # test_sinkhorn_periodic_state_shortcut_is_bit_exact); how much it saves depends on the data.
         os.environ["KCCOT_SK_NO_SHORTCUT"] = "0"
-        extra = {}
-        for regime, seed in (("near", 0), ("far", 1)):
-            _, tr = make_inputs(SHAPE["B"], seed, dev, regime)
-            for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
-                tr[k].requires_grad_(True)
+        from kccotgan_amd.graph import GraphedLossStep
+
+        def timed(fn):
             for _ in range(args.warmup):
-                l2, _g = loss_step(G, tr)
+                r = fn()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                l2, _g = loss_step(G, tr)
+                r = fn()
             torch.cuda.synchronize()
-            extra[regime] = {"ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3, "loss": float(l2),
-                             "sinkhorn_iters": G.last_info["compute_sinkhorn_loss"].tolist(),
-                             "sinkhorn_iters_executed": G.last_info["compute_sinkhorn_loss_executed"].tolist()}
+            return (time.perf_counter() - t1) / args.steps * 1e3, r
+
+        extra = {}
+        for regime, seed in (("near", 0), ("far", 1)):
+            _, tr = make_inputs(SHAPE["B"], seed, dev, regime)
+            gs = GraphedLossStep(tr, SC)
+            ms_g, (l2, _g) = timed(lambda: gs())
+            for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
+                tr[k].requires_grad_(True)
+            ms_e, _r = timed(lambda: loss_step(G, tr))
+            extra[regime] = {"ms_per_step": ms_g, "ms_per_step_eager_launches": ms_e, "loss": float(l2),
+                             "sinkhorn_iters": gs.nits.tolist(), "sinkhorn_iters_executed": gs.nits_executed.tolist()}
         out["with_exact_shortcut"] = extra
         os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
+        out["eager_launches_ms_per_step"] = timed(lambda: loss_step(G, t))[0]     # shortcut off, like the headline
     if rank == 0 and world == 1:
         kt, K = time_cost_kernel(t)
         B, T, J = SHAPE["B"], SHAPE["T"], SHAPE["J"]

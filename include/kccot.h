@@ -149,6 +149,30 @@ int kccot_sinkhorn_divergence_bwd_f32(const float* C3, const float* u_hist, cons
                                       const int32_t* nits, int n, float eps, int L, const float* gloss,
                                       float* dC3_out, void* ws, size_t ws_bytes, kccot_stream_t stream);
 
+/* compute_sinkhorn_loss (gan_utils.py:204-227) in ONE call each way -- what a binding of the
+ * reference's loss function calls.  These only sequence the stage entry points above (cost3 ->
+ * sinkhorn_divergence_fwd; sinkhorn_divergence_bwd -> cost3_bwd) so that the caller pays one FFI
+ * crossing per direction.
+ *   forward : writes C3 [3,B,B], u_hist / v_hist [3,max(L,1),B], cost3_out [3], nits_out [6]
+ *             (see kccot_sinkhorn_fwd_f32), loss_out [1].  `ticket`: one device int32, zero on entry.
+ *   backward: gloss = ONE device float; C3 / u_hist / v_hist / nits as written by the forward;
+ *             dfake [B,K], dh_fake, dh_real, dm_real, dm_fake [B,T,J] -- each may be NULL.
+ * Workspace (both directions): kccot_sinkhorn_loss_workspace_bytes(B, K). */
+size_t kccot_sinkhorn_loss_workspace_bytes(int B, int64_t K);
+int kccot_sinkhorn_loss_fwd_f32(const float* real, const float* fake, int B, int64_t K, float sc,
+                                const float* h_fake, const float* h_real, const float* m_real,
+                                const float* m_fake, int T, int J, float eps, int L, int Lmin,
+                                float thresh, unsigned flags, float* C3, float* u_hist, float* v_hist,
+                                float* cost3_out, int32_t* nits_out, float* loss_out, int32_t* ticket,
+                                void* ws, size_t ws_bytes, kccot_stream_t stream);
+int kccot_sinkhorn_loss_bwd_f32(const float* gloss, const float* real, const float* fake, int B,
+                                int64_t K, float sc, const float* h_fake, const float* h_real,
+                                const float* m_real, const float* m_fake, int T, int J, float eps,
+                                int L, const float* C3, const float* u_hist, const float* v_hist,
+                                const int32_t* nits, float* dfake, float* dh_fake, float* dh_real,
+                                float* dm_real, float* dm_fake, void* ws, size_t ws_bytes,
+                                kccot_stream_t stream);
+
 /* Mixed Sinkhorn divergence (gan_utils.py:225): loss = 2*cost3[0] - cost3[1] - cost3[2] for
  * cost3 = [W(real,fake), W(real,real), W(fake,fake)], and its backward gcost3 = gloss*[2,-1,-1].
  * All arguments are device pointers (one launch each, no host round trip). */

@@ -43,6 +43,11 @@ SIGNATURES = {
     "kccot_sinkhorn_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _i, _fp, _fp, _fp, _sz, _fp]),
     "kccot_sinkhorn_divergence_fwd_f32": (_i, [_fp, _i, _f, _i, _i, _f, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "kccot_sinkhorn_divergence_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _f, _i, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_sinkhorn_loss_workspace_bytes": (_sz, [_i, _i64]),
+    "kccot_sinkhorn_loss_fwd_f32": (_i, [_fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _f, _i, _i, _f, _u,
+                                         _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_sinkhorn_loss_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _f, _i,
+                                         _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "kccot_mixed_divergence_fwd_f32": (_i, [_fp, _fp, _fp]),
     "kccot_mixed_divergence_bwd_f32": (_i, [_fp, _fp, _fp]),
     "kccot_martingale_fwd_f32": (_i, [_fp, _i, _i, _i, _f, _f, _fp, _fp]),

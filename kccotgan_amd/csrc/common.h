@@ -34,6 +34,13 @@ inline int launch_status(const char* what) {
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- wave-level reductions (64-wide wavefront; xor butterflies leave the result in every lane)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (vmcnt(0)), which would put every outstanding global store / prefetch load on the critical
+// path of a loop that synchronises through LDS alone; LDS visibility needs lgkmcnt(0) + s_barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -60,9 +60,12 @@ __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_log
 // Diagnostic build only (-DKCCOT_DIAG, libkccot_diag.so, tools/diag_sinkhorn.py): in-kernel
 // s_memtime stamps of one half-step.  The product library contains no stamp.
 #ifdef KCCOT_DIAG
+#ifndef KCCOT_DIAG_IT
+#define KCCOT_DIAG_IT 50
+#endif
 #define KCCOT_STAMP(SLOT)                                                                         \
     do {                                                                                          \
-        if (a.diag && it == 50) {                                                                 \
+        if (a.diag && it == KCCOT_DIAG_IT) {                                                                 \
             unsigned long long tt_;                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                    \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");          \
@@ -171,8 +174,8 @@ __device__ __forceinline__ void load_costs(const float* __restrict__ C, int n, i
     }
 }
 
-template <int EPT, int LPR>
-__global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
+template <int EPT, int LPR, bool SHORTCUT>
+__device__ __forceinline__ void sinkhorn_fwd_body(const SinkArgs& a) {
     // padded so that the float4 reads of lines past n stay inside the arrays
     __shared__ __attribute__((aligned(16))) float u_s[SK_MAXN + 16 * 16];
     __shared__ __attribute__((aligned(16))) float v_s[SK_MAXN + 16 * 16];
@@ -194,20 +197,31 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
 
     // EXACT shortcut.  One iteration is a deterministic function of the state (u,v).  As soon as the
     // state after iteration k equals, bit for bit, the state after iteration k-p (p <= 4) the
-    // sequence is periodic from there on, and the state after any later iteration K is the stored
-    // state k - p + ((K-k) mod p): nothing is approximated, the loop is merely not re-executed.
+    // sequence is periodic from there on, and the state after any later iteration K is a stored
+    // state congruent to K modulo p: nothing is approximated, the loop is merely not re-executed.
     // (Sharp problems -- costs of O(1e3) against eps = 1, the GAN regime -- reach an fp32 fixed point
     // within a handful of iterations.)  The kernel jumps to one iteration before the first point at
     // which the reference's stop rule could fire (or before L), fills the history the backward
     // needs, and resumes the ordinary loop, so the stop logic and the final iterate are computed
     // by the same code as without the shortcut.  nits_out[p] is the reference-equivalent iteration
     // count; nits_out[nprob + p] the number of iterations actually executed.
+    //
+    // Detection costs no LDS round trip on the critical path: every lane keeps its line's last four
+    // duals in registers and compares in place; one ballot per candidate period folds the wave's
+    // lines, lane 0 ORs the wave's mismatch mask into an LDS word, and the word is read back after
+    // the closing barrier but only CONSUMED one iteration later (its latency hides under the next
+    // half-step).  The ring of the last four states in LDS is written every iteration and read
+    // only at the jump.
     __shared__ float ring_u[4][SK_MAXN], ring_v[4][SK_MAXN];
-    __shared__ int mis[2];
-    if (t < 2) mis[t] = 0;
-    __syncthreads();
-    bool detect = a.shortcut != 0;
+    __shared__ int mis[4];
+    if (SHORTCUT) {
+        if (t < 4) mis[t] = 0;
+        __syncthreads();
+    }
+    bool detect = SHORTCUT;
     int computed = 0;
+    int mprev = ~0;                       // mismatch mask of the previous iteration (bit p: state != state p iterations earlier)
+    float pu2 = 0.f, pu3 = 0.f, pu4 = 0.f, pv2 = 0.f, pv3 = 0.f, pv4 = 0.f;
 
     int nits = 0;
     float ui = 0.f, vj = 0.f;   // this line's duals (every lane of the line holds them)
@@ -217,37 +231,44 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
         const float un = half_step<EPT, LPR, true>(crow, ui, v_s, q, lw2);
         KCCOT_STAMP(1);
         const float du = (active && q == 0) ? fabsf(un - ui) : 0.f;
-        ui = un;
         int bits = 0;
+        if (SHORTCUT && detect) {
+            const unsigned b = __float_as_uint(un);
+            bits = (b != __float_as_uint(ui) ? 2 : 0) | (b != __float_as_uint(pu2) ? 4 : 0) |
+                   (b != __float_as_uint(pu3) ? 8 : 0) | (b != __float_as_uint(pu4) ? 16 : 0);
+            pu4 = pu3; pu3 = pu2; pu2 = ui;
+        }
+        ui = un;
         if (active && q == 0) {
             u_s[line] = un;
             if (a.u_hist) a.u_hist[((int64_t)p * a.L + it) * n + line] = un;
-            if (detect) {
-#pragma unroll
-                for (int pp = 1; pp <= 4; ++pp)
-                    if (it >= pp && __float_as_uint(un) != __float_as_uint(ring_u[(it - pp) & 3][line])) bits |= 1 << pp;
-                ring_u[it & 3][line] = un;
-            }
+            if (SHORTCUT && detect) ring_u[it & 3][line] = un;
         }
         KCCOT_STAMP(2);
-        __syncthreads();
+        lds_barrier();      // the history stores stay in flight (nothing in this kernel reads them back)
         KCCOT_STAMP(3);
         const float vn = half_step<EPT, LPR, false>(ccol, vj, u_s, q, lw2);
         KCCOT_STAMP(4);
+        if (SHORTCUT && detect) {
+            const unsigned b = __float_as_uint(vn);
+            bits |= (b != __float_as_uint(vj) ? 2 : 0) | (b != __float_as_uint(pv2) ? 4 : 0) |
+                    (b != __float_as_uint(pv3) ? 8 : 0) | (b != __float_as_uint(pv4) ? 16 : 0);
+            pv4 = pv3; pv3 = pv2; pv2 = vj;
+            if (!active) bits = 0;
+            int wb = 0;
+#pragma unroll
+            for (int pp = 1; pp <= 4; ++pp)
+                if (__builtin_amdgcn_ballot_w64((bits >> pp) & 1)) wb |= 1 << pp;
+            if ((t & 63) == 0 && wb) atomicOr(&mis[it & 3], wb);
+        }
         vj = vn;
         if (active && q == 0) {
             v_s[line] = vn;
             if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + line] = vn;
-            if (detect) {
-#pragma unroll
-                for (int pp = 1; pp <= 4; ++pp)
-                    if (it >= pp && __float_as_uint(vn) != __float_as_uint(ring_v[(it - pp) & 3][line])) bits |= 1 << pp;
-                ring_v[it & 3][line] = vn;
-                if (bits) atomicOr(&mis[it & 1], bits);
-            }
+            if (SHORTCUT && detect) ring_v[it & 3][line] = vn;
         }
         KCCOT_STAMP(5);
-        __syncthreads();
+        lds_barrier();
         KCCOT_STAMP(6);
         nits = it + 1;
         ++computed;
@@ -258,13 +279,16 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
             const float err = block_sum(du, red) * err_scale;
             if (a.thresh > err) break;
         }
-        if (detect) {
-            const int m = mis[it & 1];
-            if (t == 0) mis[(it + 1) & 1] = 0;
+        if (SHORTCUT && detect) {
+            const int mcur = mis[it & 3];                 // consumed at the end of the NEXT iteration
+            if (t == 0) mis[(it + 2) & 3] = 0;
+            // mprev describes iteration it-1: bit pp clear <=> S_it == S_{it-pp} (valid for it-1 >= pp)
             int per = 0;
 #pragma unroll
             for (int pp = 4; pp >= 1; --pp)
-                if (it >= pp && !((m >> pp) & 1)) per = pp;          // smallest matching period
+                if (it - 1 >= pp && !((mprev >> pp) & 1)) per = pp;          // smallest matching period
+            mprev = mcur;
+            KCCOT_STAMP(7);
             if (per) {
                 detect = false;
                 // first iteration count at which the reference could leave its loop early
@@ -272,19 +296,18 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
                 if (first_stop < 1) first_stop = 1;
                 const int K1 = (a.L < first_stop ? a.L : first_stop) - 1;   // resume so that iteration K1+1 is real
                 if (K1 > nits) {
-                    // S_k for k > nits is S_{src(k)}, src(k) = nits if (k-nits) % per == 0 else nits - per + (k-nits) % per;
-                    // S_k lives in ring slot (k-1) & 3
+                    // the states from S_{it-per} on have period per, and the ring holds S_{nits-3..nits}
+                    // (S_k in slot (k-1) & 3): S_k = S_src(k), src(k) = lo + (k - lo) mod per, lo = nits-per+1
+                    const int lo = nits - per + 1;
                     if (a.u_hist) {
                         for (int e = t; e < (K1 - nits) * n; e += blockDim.x) {
-                            const int k = nits + 1 + e / n, i = e % n, r = (k - nits) % per;
-                            const int slot = ((r == 0 ? nits : nits - per + r) - 1) & 3;
+                            const int k = nits + 1 + e / n, i = e % n;
+                            const int slot = (lo + (k - lo) % per - 1) & 3;
                             a.u_hist[((int64_t)p * a.L + (k - 1)) * n + i] = ring_u[slot][i];
                             a.v_hist[((int64_t)p * a.L + (k - 1)) * n + i] = ring_v[slot][i];
                         }
                     }
-                    const int r = (K1 - nits) % per;
-                    const int slot = ((r == 0 ? nits : nits - per + r) - 1) & 3;
-                    __syncthreads();
+                    const int slot = (lo + (K1 - lo) % per - 1) & 3;
                     if (t < n) { u_s[t] = ring_u[slot][t]; v_s[t] = ring_v[slot][t]; }
                     __syncthreads();
                     ui = u_s[active ? line : 0];
@@ -334,6 +357,12 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) {
     }
 }
 
+// the default (exact periodic-state shortcut compiled in) and the every-iteration variant
+template <int EPT, int LPR>
+__global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg(SinkArgs a) { sinkhorn_fwd_body<EPT, LPR, true>(a); }
+template <int EPT, int LPR>
+__global__ __launch_bounds__(SK_MAXT) void sinkhorn_fwd_reg_full(SinkArgs a) { sinkhorn_fwd_body<EPT, LPR, false>(a); }
+
 // ------------------------------------------------------------------------------------------
 // reverse sweep
 //   u_t,i = a - eps*LSE_j((-C_ij + u_{t-1,i} + v_{t-1,j})/eps) + u_{t-1,i},  a = eps*log(1/n)
@@ -364,7 +393,6 @@ struct SinkBwdArgs {
     int n, L;
     float eps, inv_eps;
     int div_weights;      // 1: gcost[p] = {2,-1,-1}[p] * gcost[0]   (d(2 xy - xx - yy), gan_utils.py:225)
-    int shortcut;         // 1: leave the sweep once the carried gradient is exactly zero
 };
 
 template <int EPT, int LPR>
@@ -374,13 +402,11 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float V[2][PADN];
     __shared__ __attribute__((aligned(16))) float gu[PADN];
     __shared__ __attribute__((aligned(16))) float gv[PADN];
-    __shared__ int nz[2];
     const int p = blockIdx.x, n = a.n;
     const int t = threadIdx.x, line = t / LPR, q = t % LPR;
     const bool active = line < n;
     const float* C = a.C + (int64_t)p * n * n;
     const float k2 = a.inv_eps * LOG2E;
-    if (t < 2) nz[t] = 0;
     const float g = a.div_weights ? (p == 0 ? 2.0f : -1.0f) * a.gcost[0] : a.gcost[p];
     const int nits = a.nits[p];
     const float* uh = a.u_hist + (int64_t)p * a.L * n;
@@ -459,7 +485,7 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
             // grad wrt u_t: the final-cost term on the last iteration, nothing on older ones
             if (active && q == 0) gu[line] = (it == nits ? gu[line] : 0.f) - s;
         }
-        __syncthreads();
+        lds_barrier();      // LDS-only: the history prefetch (nu, nv) stays in flight across it
         // refill the slots the older iteration needs: U[(it-1)&1] <- U_{it-1}, V[it&1] <- V_{it-2}
         // (V_t is dead after pass A; U_{it-1}'s slot was last read in iteration it+1)
         if (t < n) {
@@ -482,18 +508,9 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
                 r += w;
             }
             r = seg_sum<LPR>(r);
-            if (active && q == 0) {
-                gv[line] = -r;
-                if (r != 0.f) atomicOr(&nz[it & 1], 1);
-            }
+            if (active && q == 0) gv[line] = -r;
         }
-        __syncthreads();
-        // EXACT early exit: the only state carried to the older iterations is gv (gu restarts from 0).
-        // If every gv is +-0 then every further increment Q*gv, P*gu is exactly 0 and the rest of the
-        // sweep cannot change dC by a single bit.
-        const int any = nz[it & 1];
-        if (t == 0) nz[(it + 1) & 1] = 0;
-        if (a.shortcut && !any) break;
+        lds_barrier();
     }
 
     // dC = row-layout part + (column-layout part)^T
@@ -619,7 +636,11 @@ extern "C" int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float ep
     a.diag = static_cast<unsigned long long*>(ws);   // diagnostic build: ws carries the stamp buffer
 #endif
     hipStream_t st = (hipStream_t)stream;
-    KCCOT_SK_DISPATCH(sinkhorn_fwd_reg, a, g, nprob, st)
+    if (a.shortcut) {
+        KCCOT_SK_DISPATCH(sinkhorn_fwd_reg, a, g, nprob, st)
+    } else {
+        KCCOT_SK_DISPATCH(sinkhorn_fwd_reg_full, a, g, nprob, st)
+    }
     return launch_status("sinkhorn_fwd_reg");
 }
 
@@ -635,8 +656,7 @@ extern "C" int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const
         return launch_sinkhorn_bwd_gen(C, u_hist, v_hist, nits, nprob, n, eps, L, gcost, dC_out, ws, ws_bytes,
                                        (hipStream_t)stream);
     SinkGeom g = sink_geom(n);
-    SinkBwdArgs a{C, u_hist, v_hist, nits, gcost, dC_out, n, L, eps, (float)(1.0 / (double)eps), g_div_weights,
-                  sink_shortcut_enabled()};
+    SinkBwdArgs a{C, u_hist, v_hist, nits, gcost, dC_out, n, L, eps, (float)(1.0 / (double)eps), g_div_weights};
     hipStream_t st = (hipStream_t)stream;
     KCCOT_SK_DISPATCH(sinkhorn_bwd_reg, a, g, nprob, st)
     return launch_status("sinkhorn_bwd_reg");

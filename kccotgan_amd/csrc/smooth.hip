@@ -148,13 +148,6 @@ __global__ __launch_bounds__(256) void maxnorm_bwd_apply(const float* __restrict
 // ------------------------------------------------------------------------------------------
 constexpr int SP_PPT = 4;
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
-// counter when stores are outstanding, which would serialise every plane behind its own output
-// store and the prefetch of the next plane; LDS visibility needs lgkmcnt(0) + s_barrier only.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 struct PlaneArgs {
     const float* in;       // forward: input video; adjoint: gout
     const float* out_fwd;  // adjoint only: the forward's normalised output (arg-max detection)

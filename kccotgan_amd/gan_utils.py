@@ -247,6 +247,69 @@ class _SinkhornDivergence(torch.autograd.Function):
         return dC, None, None, None, None
 
 
+def _pad64(n):
+    return (n + 63) & ~63
+
+
+class _SinkhornLoss(torch.autograd.Function):
+    """compute_sinkhorn_loss as ONE library call each way (kccot_sinkhorn_loss_{fwd,bwd}_f32): cost
+    assembly + the three solves + their combination; reverse sweep + cost backward.  Same kernels as
+    _Cost3 followed by _SinkhornDivergence, a third of the host work."""
+
+    @staticmethod
+    def forward(ctx, real, fake, h_fake, h_real, m_real, m_fake, sc, eps, L, Lmin, tag):
+        B, K = real.shape
+        if fake.shape != real.shape:
+            raise ValueError("real and fake must have the same shape: %s vs %s" % (tuple(real.shape), tuple(fake.shape)))
+        T, J = h_fake.shape[1], h_fake.shape[2]
+        for t in (h_fake, h_real, m_real, m_fake):
+            if tuple(t.shape) != (B, T, J):
+                raise ValueError("h / M must all be [%d,%d,%d]; got %s" % (B, T, J, tuple(t.shape)))
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("the loss path never differentiates w.r.t. real (kernel_train.py:252,289); "
+                                      "use compute_sinkhorn for a gradient w.r.t. both operands")
+        dev = real.device
+        keep = any(ctx.needs_input_grad[1:6])
+        Lh = max(int(L), 1)
+        nc, nh = _pad64(3 * B * B), _pad64(3 * Lh * B)
+        state = _lib.empty((nc + (2 * nh if keep else 0),), torch.float32, dev)     # C3 | u_hist | v_hist
+        C3 = state[:nc]
+        uh, vh = (state[nc:nc + nh], state[nc + nh:]) if keep else (None, None)
+        small = _lib.empty((4,), torch.float32, dev)                                 # cost3 | loss
+        nits = _lib.empty((6,), torch.int32, dev)           # [reference-equivalent counts | iterations executed]
+        ws, wsb = workspace(lib.kccot_sinkhorn_loss_workspace_bytes(B, K), real)
+        check(lib.kccot_sinkhorn_loss_fwd_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
+                                              ptr(m_fake), T, J, float(eps), int(L), int(Lmin), _THRESH, cost_flags,
+                                              ptr(C3), ptr(uh), ptr(vh), ptr(small), ptr(nits), ptr(small[3:]),
+                                              ptr(_ticket(dev)), ws, wsb, stream_of(real)), "sinkhorn_loss_fwd")
+        last_info[tag], last_info[tag + "_executed"] = nits[:3], nits[3:]
+        last_info[tag + "_costs"] = small[:3]
+        last_info[tag + "_C3"] = C3[:3 * B * B].view(3, B, B)
+        if keep:
+            ctx.save_for_backward(real, fake, h_fake, h_real, m_real, m_fake, state, nits)
+        ctx.cfg = (float(sc), float(eps), Lh)
+        return small[3:].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        real, fake, h_fake, h_real, m_real, m_fake, state, nits = ctx.saved_tensors
+        sc, eps, Lh = ctx.cfg
+        B, K = real.shape
+        T, J = h_fake.shape[1], h_fake.shape[2]
+        nc, nh = _pad64(3 * B * B), _pad64(3 * Lh * B)
+        need = ctx.needs_input_grad
+        g = g.reshape(1).contiguous().float()
+        dfake = _lib.empty_like(fake) if need[1] else None
+        feats = _lib.empty((4, B, T, J), torch.float32, real.device) if any(need[2:6]) else None
+        dhf, dhr, dmr, dmf = ((feats[i] if need[2 + i] else None) for i in range(4))
+        ws, wsb = workspace(lib.kccot_sinkhorn_loss_workspace_bytes(B, K), real)
+        check(lib.kccot_sinkhorn_loss_bwd_f32(ptr(g), ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
+                                              ptr(m_fake), T, J, eps, Lh, ptr(state[:nc]), ptr(state[nc:nc + nh]),
+                                              ptr(state[nc + nh:]), ptr(nits), ptr(dfake), ptr(dhf), ptr(dhr), ptr(dmr),
+                                              ptr(dmf), ws, wsb, stream_of(real)), "sinkhorn_loss_bwd")
+        return None, dfake, dhf, dhr, dmr, dmf, None, None, None, None, None
+
+
 class _MixedDivergence(torch.autograd.Function):
     """loss = 2*W_xy - W_xx - W_yy (gan_utils.py:225) as one launch each way."""
 
@@ -352,5 +415,6 @@ def compute_sinkhorn_loss(f_real, f_fake, scaling_coef, sinkhorn_eps, sinkhorn_l
     del video  # both layouts flatten to [B, K]
     eps, L = (float(sinkhorn_eps), int(sinkhorn_l)) if honor_eps_l else (1.0, 100)
     real, fake = _flat2(f_real), _flat2(f_fake)
-    C3 = _Cost3.apply(real, fake, _feat(h_fake), _feat(h_real), _feat(m_real), _feat(m_fake), float(scaling_coef))
-    return _SinkhornDivergence.apply(C3, eps, L, _LMIN, "compute_sinkhorn_loss")        # C3 = [xy, xx, yy]
+    # one library call each way; equivalent to _Cost3 (C3 = [xy, xx, yy]) followed by _SinkhornDivergence
+    return _SinkhornLoss.apply(real, fake, _feat(h_fake), _feat(h_real), _feat(m_real), _feat(m_fake),
+                               float(scaling_coef), eps, L, _LMIN, "compute_sinkhorn_loss")

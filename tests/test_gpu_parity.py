@@ -214,7 +214,7 @@ def _raw_sinkhorn(L, C, eps, Lc, Lmin, mode, shortcut):
         dC = torch.empty_like(C)
         gc = torch.tensor([2.0, -1.0, -1.0][:nprob], device=DEV)
         wsb = lib.kccot_sinkhorn_workspace_bytes(nprob, n)
-        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+        ws = torch.empty(max(wsb // 4, 4), device=DEV)
         assert lib.kccot_sinkhorn_fwd_f32(ptr(C), nprob, n, eps, Lc, Lmin, 1e-2, mode, ptr(uh), ptr(vh), ptr(cost),
                                           ptr(nits), ptr(pi), ptr(ws), wsb, None) == 0
         assert lib.kccot_sinkhorn_bwd_f32(ptr(C), ptr(uh), ptr(vh), ptr(nits), nprob, n, eps, Lc, ptr(gc), ptr(dC),
@@ -239,9 +239,8 @@ def _same_bits(a, b):
 
 
 def test_sinkhorn_periodic_state_shortcut_is_bit_exact(G, L):
-    """The forward skips iterations once the fp32 state (u, v) repeats bit for bit with period <= 4,
-    and the reverse sweep stops once the carried gradient is exactly zero (sinkhorn.hip).  Both claim
-    to be EXACT: every output -- cost, plan, iteration count, the full dual history, dC -- must be
+    """The forward skips iterations once the fp32 state (u, v) repeats bit for bit with period <= 4
+    (sinkhorn.hip).  It claims to be EXACT: every output -- cost, plan, iteration count, the full dual history, dC -- must be
     bit-identical to a run that executes every iteration (KCCOT_SK_NO_SHORTCUT=1)."""
     probs = {}
     for name, (shape, seed, regime) in dict(near=("cfg2", 0, "near"), far=("cfg2", 1, "far"), small=SMALL[0]).items():
@@ -524,3 +523,62 @@ def test_rbf_mmd_matches_sklearn_definition():
         m2 = mmd.rbf_mmd2(torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV), gamma=g)
         want2 = rbf_kernel(x, x, g).mean() + rbf_kernel(y, y, g).mean() - 2 * rbf_kernel(x, y, g).mean()
         assert abs(float(m2) - want2) < 1e-5 * max(abs(want2), 1e-3)
+
+
+# ---------------------------------------------------------------- one-call loss and graph capture
+def test_one_call_loss_equals_staged_path(G, L):
+    """kccot_sinkhorn_loss_{fwd,bwd}_f32 only sequence the stage entry points: bit-identical to
+    _Cost3 followed by _SinkhornDivergence, values and gradients."""
+    for shape, seed, regime in (SMALL[0], ("cfg2", 1, "far")):
+        g, inp, t = load(shape, seed, regime)
+        wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]
+        outs = []
+        for fused in (True, False):
+            tt = {k: v.clone().requires_grad_(k in wrt) for k, v in t.items()}
+            if fused:
+                loss = G.compute_sinkhorn_loss(tt["real"], tt["fake"], cases.SC, 0.8, 100, tt["h_fake"], tt["m_real"],
+                                               tt["h_real"], tt["m_fake"], video=True)
+            else:
+                C3 = G._Cost3.apply(G._flat2(tt["real"]), G._flat2(tt["fake"]), G._feat(tt["h_fake"]), G._feat(tt["h_real"]),
+                                    G._feat(tt["m_real"]), G._feat(tt["m_fake"]), float(cases.SC))
+                loss = G._SinkhornDivergence.apply(C3, 1.0, 100, 100, "staged")
+            grads = torch.autograd.grad(loss, [tt[k] for k in wrt])
+            outs.append([loss.detach().reshape(1)] + [x.reshape(-1) for x in grads])
+        for a, b in zip(*outs):
+            assert _same_bits(a.cpu().numpy(), b.cpu().numpy())
+
+
+def test_graphed_loss_is_bit_identical(G, L):
+    """A captured hipGraph replays the eager kernels with the eager arguments: same bits; and a replay
+    after new inputs were copied into the static buffers follows them."""
+    from kccotgan_amd.graph import GraphedLossStep, graphed_loss
+    shape, seed, regime = SMALL[0]
+    g, inp, t = load(shape, seed, regime)
+    wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]
+
+    def eager(tt):
+        tt = {k: v.clone().requires_grad_(k in wrt) for k, v in tt.items()}
+        loss = G.compute_sinkhorn_loss(tt["real"], tt["fake"], cases.SC, 0.8, 100, tt["h_fake"], tt["m_real"],
+                                       tt["h_real"], tt["m_fake"], video=True)
+        return loss.detach(), dict(zip(wrt, torch.autograd.grad(loss, [tt[k] for k in wrt])))
+
+    step = GraphedLossStep(t, cases.SC)
+    t2 = {k: (v * 0.5 + 0.25 * torch.rand_like(v)) for k, v in t.items()}
+    for cur in (t, t2, t):
+        loss, grads = step(**cur)
+        eloss, egrads = eager(cur)
+        torch.cuda.synchronize()
+        assert _same_bits(loss.reshape(1).cpu().numpy(), eloss.reshape(1).cpu().numpy())
+        for k in wrt:
+            assert _same_bits(grads[k].cpu().numpy(), egrads[k].cpu().numpy()), k
+    # forward / backward captured separately, inside a larger autograd graph
+    sample = {k: v.clone().requires_grad_(k in wrt) for k, v in t.items()}
+    f = graphed_loss(sample, cases.SC)
+    tt = {k: v.clone().requires_grad_(k in wrt) for k, v in t2.items()}
+    scale = torch.tensor(-1.0, device=DEV)
+    out = f(tt["real"], tt["fake"] * 1.0, tt["h_fake"], tt["m_real"], tt["h_real"], tt["m_fake"]) * scale
+    out.backward()
+    eloss, egrads = eager(t2)
+    assert _same_bits(out.detach().reshape(1).cpu().numpy(), (-eloss).reshape(1).cpu().numpy())
+    for k in wrt:
+        np.testing.assert_array_equal(tt[k].grad.cpu().numpy(), -egrads[k].cpu().numpy())
