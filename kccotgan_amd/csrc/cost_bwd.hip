@@ -20,13 +20,13 @@ enum CoeffMode { CO_LOSS3_DFAKE = 0, CO_DX = 1, CO_DY = 2, CO_SAME = 3 };
 // R = n1 + n2 stack rows: first the n1 rows of src1, then the n2 rows of src2.
 // One block per output row m: thread r writes Wt[r][m]; the row / column sums that sit on the
 // diagonal are a block reduction (no serial loop).
-__global__ __launch_bounds__(256) void build_coeffs(int mode, const float* __restrict__ g, const float* __restrict__ g2,
-                                                    int Bx, int By, float sc, float* __restrict__ Wt) {
+__device__ __forceinline__ void build_coeffs_body(int m, int mode, const float* __restrict__ g,
+                                                  const float* __restrict__ g2, int Bx, int By, float sc,
+                                                  float* __restrict__ Wt) {
     // g: [Bx,By] (LOSS3: gxy [B,B]); g2: LOSS3 only: gyy [B,B]
     __shared__ float red[16];
     const int Bout = (mode == CO_DY) ? By : (mode == CO_LOSS3_DFAKE ? By : Bx);
     const int R = (mode == CO_SAME) ? Bx : Bx + By;
-    const int m = blockIdx.x;
     const float two_sc = 2.f * sc;
     // diagonal sum for this m
     float part = 0.f;
@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256) void build_coeffs(int mode, const float* __res
         }
         Wt[(int64_t)r * Bout + m] = w;
     }
+}
+
+__global__ __launch_bounds__(256) void build_coeffs(int mode, const float* __restrict__ g, const float* __restrict__ g2,
+                                                    int Bx, int By, float sc, float* __restrict__ Wt) {
+    build_coeffs_body(blockIdx.x, mode, g, g2, Bx, By, sc, Wt);
 }
 
 // out[m0+mm][k] = sum_r Wt[r][m0+mm] * Z_r[k];  one column k per thread, MB output rows per block row.
@@ -118,11 +123,11 @@ struct CausalGradJob {
 };
 struct CausalGradBatch { CausalGradJob job[4]; int njobs; };
 
-__global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, int J, float sc) {
+__device__ __forceinline__ void causal_grads_body(const CausalGradBatch& cb, int T, int J, float sc, int bx, int by, int bz) {
     __shared__ float sg[16 * 65], sx[64 * 17];
-    const CausalGradJob& jb = cb.job[blockIdx.z];
+    const CausalGradJob& jb = cb.job[bz];
     const int TJ = T * J, KK = (T - 1) * J;
-    const int a0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
+    const int a0 = by * 16, k0 = bx * 16;
     if (a0 >= jb.Ba) return;   // block-uniform
     const int t = threadIdx.x, ta = t >> 4, tk = t & 15;
     // g is [Bi,Bj] with row pitch jb.pitch (= Bj): for CG_H `a` indexes its rows and b its columns,
@@ -135,25 +140,34 @@ __global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, i
         const float* src = jb.src[term];
         if (!g) continue;
         for (int b0 = 0; b0 < jb.Bb; b0 += 64) {
+            // addresses clamped into range, zeros selected afterwards: the eight to twelve loads of a
+            // thread carry no control dependence and are all in flight before the first wait
+            float gv[4], xa[4], xb[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int e = t + 256 * m;
-                if (jb.mode == CG_H) {
-                    const int ar = e >> 6, bb = e & 63;
-                    sg[ar * 65 + bb] = (a0 + ar < jb.Ba && b0 + bb < jb.Bb) ? g[(int64_t)(ab + a0 + ar) * Bj + b0 + bb] : 0.f;
-                } else {
-                    const int bb = e >> 4, ar = e & 15;
-                    sg[ar * 65 + bb] = (a0 + ar < jb.Ba && b0 + bb < jb.Bb) ? g[(int64_t)(b0 + bb) * Bj + ab + a0 + ar] : 0.f;
-                }
+                const int ar = (jb.mode == CG_H) ? (e >> 6) : (e & 15), bg = (jb.mode == CG_H) ? (e & 63) : (e >> 4);
+                const int ac = (a0 + ar < jb.Ba) ? a0 + ar : jb.Ba - 1, bc = (b0 + bg < jb.Bb) ? b0 + bg : jb.Bb - 1;
+                gv[m] = (jb.mode == CG_H) ? g[(int64_t)(ab + ac) * Bj + bc] : g[(int64_t)bc * Bj + ab + ac];
+                const int bb = e >> 4, k = k0 + (e & 15);
+                const int bx = (b0 + bb < jb.Bb) ? b0 + bb : jb.Bb - 1;
+                const float* row = src + (int64_t)bx * TJ;
+                const int kc = k < TJ ? k : TJ - 1;
+                // CG_H: row[k+J] - row[k] (k < KK);  CG_M: row[k-J] (k >= J) - row[k] (k < KK)
+                const int ka = (jb.mode == CG_H) ? (kc < KK ? kc + J : kc) : (kc >= J ? kc - J : kc);
+                xa[m] = row[ka];
+                xb[m] = row[kc];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int e = t + 256 * m;
+                const int ar = (jb.mode == CG_H) ? (e >> 6) : (e & 15), bg = (jb.mode == CG_H) ? (e & 63) : (e >> 4);
+                sg[ar * 65 + bg] = (a0 + ar < jb.Ba && b0 + bg < jb.Bb) ? gv[m] : 0.f;
                 const int bb = e >> 4, kk = e & 15, k = k0 + kk;
                 float x = 0.f;
                 if (b0 + bb < jb.Bb && k < TJ) {
-                    const float* row = src + (int64_t)(b0 + bb) * TJ;
-                    if (jb.mode == CG_H) {
-                        if (k < KK) x = row[k + J] - row[k];
-                    } else {
-                        x = (k >= J ? row[k - J] : 0.f) - (k < KK ? row[k] : 0.f);
-                    }
+                    if (jb.mode == CG_H) x = (k < KK) ? xa[m] - xb[m] : 0.f;
+                    else x = (k >= J ? xa[m] : 0.f) - (k < KK ? xb[m] : 0.f);
                 }
                 sx[bb * 17 + kk] = x;
             }
@@ -165,6 +179,24 @@ __global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, i
     }
     const int aa = a0 + ta, k = k0 + tk;
     if (aa < jb.Ba && k < TJ) jb.out[(int64_t)aa * TJ + k] = tot * sc;
+}
+
+__global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, int J, float sc) {
+    causal_grads_body(cb, T, J, sc, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The coefficient matrix of the video gradient and the feature gradients both depend on dC alone:
+// one launch, the first `nbuild` workgroups build W, the others are the causal_grads grid linearised.
+__global__ __launch_bounds__(256) void coeffs_and_causal_grads(int mode, const float* __restrict__ g,
+                                                               const float* __restrict__ g2, int Bx, int By, float sc,
+                                                               float* __restrict__ Wt, int nbuild, CausalGradBatch cb,
+                                                               int T, int J, int gx, int gy) {
+    if ((int)blockIdx.x < nbuild) {
+        build_coeffs_body(blockIdx.x, mode, g, g2, Bx, By, sc, Wt);
+    } else {
+        const int lin = blockIdx.x - nbuild;
+        causal_grads_body(cb, T, J, sc, lin % gx, (lin / gx) % gy, lin / (gx * gy));
+    }
 }
 
 static int launch_causal_grads(CausalGradBatch& cb, int T, int J, float sc, hipStream_t st) {
@@ -304,16 +336,6 @@ extern "C" int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* r
     const int64_t bb = (int64_t)B * B;
     const float *gxy = g3, *gxx = g3 + bb, *gyy = g3 + 2 * bb;
     int rc;
-    if (dfake) {
-        const size_t need = kccot_pairwise_cost3_bwd_workspace_bytes(B, K);
-        if (!ws || ws_bytes < need)
-            return fail(KCCOT_EWORKSPACE, "pairwise_cost3_bwd: workspace %zu < required %zu", ws_bytes, need);
-        float* Wt = static_cast<float*>(ws);
-        hipLaunchKernelGGL(build_coeffs, dim3(B), dim3(256), 0, st, (int)CO_LOSS3_DFAKE,
-                           gxy, gyy, B, B, sc, Wt);
-        if ((rc = launch_status("build_coeffs"))) return rc;
-        if ((rc = launch_apply(Wt + row_begin, B, real, B, fake, B, row_count, K, dfake, st))) return rc;
-    }
     // gan_utils.py:221-223: h_fake rows of xy (cols m_real) and of yy (cols m_fake); h_real rows of xx
     // (cols m_real); m_real cols of xy (rows h_fake) and of xx (rows h_real); m_fake cols of yy (rows h_fake)
     CausalGradBatch cg{};
@@ -321,7 +343,21 @@ extern "C" int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* r
     if (dh_real) cg.job[cg.njobs++] = CausalGradJob{dh_real, CG_H, row_count, B, row_begin, B, {gxx, nullptr}, {m_real, nullptr}};
     if (dm_real) cg.job[cg.njobs++] = CausalGradJob{dm_real, CG_M, row_count, B, row_begin, B, {gxy, gxx}, {h_fake, h_real}};
     if (dm_fake) cg.job[cg.njobs++] = CausalGradJob{dm_fake, CG_M, row_count, B, row_begin, B, {gyy, nullptr}, {h_fake, nullptr}};
-    return launch_causal_grads(cg, T, J, sc, st);
+    if (!dfake) return launch_causal_grads(cg, T, J, sc, st);
+    const size_t need = kccot_pairwise_cost3_bwd_workspace_bytes(B, K);
+    if (!ws || ws_bytes < need)
+        return fail(KCCOT_EWORKSPACE, "pairwise_cost3_bwd: workspace %zu < required %zu", ws_bytes, need);
+    float* Wt = static_cast<float*>(ws);
+    if (cg.njobs == 0) {
+        hipLaunchKernelGGL(build_coeffs, dim3(B), dim3(256), 0, st, (int)CO_LOSS3_DFAKE, gxy, gyy, B, B, sc, Wt);
+        if ((rc = launch_status("build_coeffs"))) return rc;
+    } else {
+        const int gx = (T * J + 15) / 16, gy = (row_count + 15) / 16;
+        hipLaunchKernelGGL(coeffs_and_causal_grads, dim3(B + gx * gy * cg.njobs), dim3(256), 0, st, (int)CO_LOSS3_DFAKE,
+                           gxy, gyy, B, B, sc, Wt, B, cg, T, J, gx, gy);
+        if ((rc = launch_status("coeffs_and_causal_grads"))) return rc;
+    }
+    return launch_apply(Wt + row_begin, B, real, B, fake, B, row_count, K, dfake, st);
 }
 
 extern "C" int kccot_pairwise_cost3_bwd_f32(const float* g3, const float* real, const float* fake, int B,

@@ -39,39 +39,48 @@ struct CostPlan {
 // flattened h rows and first differences of the flattened M rows (M[k+J] - M[k]); both are
 // staged through LDS in CAUSAL_KC-wide k chunks ((T-1)*J = 232 fits in one at the default T = 30,
 // J = 8) so that global reads are coalesced and all issued before the single wait.
-// sh, sm: CAUSAL_TILE*CAUSAL_PITCH floats of LDS each.  Every thread of the block must call it.
+// sh, sm: CAUSAL_TILE*CAUSAL_PITCH floats of LDS each (per team).  Every thread of the block must call it.
 constexpr int CAUSAL_TILE = 16;
 constexpr int CAUSAL_KC = 256;
 constexpr int CAUSAL_PITCH = CAUSAL_KC + 4;   // 260: rows 16-byte aligned and 4 banks apart -> conflict-free ds_read_b128
 
 __device__ __forceinline__ float causal_tile16(const float* __restrict__ h, const float* __restrict__ M, int i0,
-                                               int j0, int Bx, int By, int T, int J, float* sh, float* sm) {
-    const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
+                                               int j0, int Bx, int By, int T, int J, float* sh, float* sm,
+                                               int t = threadIdx.x) {
+    // t: the caller's index 0..255 inside its 256-thread tile team (a 1024-thread block runs four teams)
+    const int ti = t >> 4, tj = t & 15;
     const int KK = (T - 1) * J, TJ = T * J;
-    float tot = 0.f;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;   // four independent chains of 64 FMAs per chunk
     for (int k0 = 0; k0 < KK; k0 += CAUSAL_KC) {
+        // every address is clamped into range so that the 48 loads carry no control dependence and are
+        // all in flight before the first wait; out-of-range lanes are zeroed by the selects below
+        const int k = k0 + t;
+        const bool kok = k < KK;
+        const int kc = kok ? k : 0;
+        float hv[CAUSAL_TILE], m0[CAUSAL_TILE], m1[CAUSAL_TILE];
 #pragma unroll
         for (int m = 0; m < CAUSAL_TILE; ++m) {
-            const int row = m, kk = t, k = k0 + kk;
-            const bool kok = k < KK;
-            sh[row * CAUSAL_PITCH + kk] = (kok && i0 + row < Bx) ? h[(int64_t)(i0 + row) * TJ + k] : 0.f;
-            float d = 0.f;
-            if (kok && j0 + row < By) {
-                const float* mr = M + (int64_t)(j0 + row) * TJ + k;
-                d = mr[J] - mr[0];
-            }
-            sm[row * CAUSAL_PITCH + kk] = d;
+            const int ri = (i0 + m < Bx) ? i0 + m : Bx - 1, rj = (j0 + m < By) ? j0 + m : By - 1;
+            hv[m] = h[(int64_t)ri * TJ + kc];
+            const float* mr = M + (int64_t)rj * TJ + kc;
+            m0[m] = mr[0];
+            m1[m] = mr[J];
+        }
+#pragma unroll
+        for (int m = 0; m < CAUSAL_TILE; ++m) {
+            sh[m * CAUSAL_PITCH + t] = (kok && i0 + m < Bx) ? hv[m] : 0.f;
+            sm[m * CAUSAL_PITCH + t] = (kok && j0 + m < By) ? m1[m] - m0[m] : 0.f;
         }
         __syncthreads();
 #pragma unroll 8
         for (int kk = 0; kk < CAUSAL_KC; kk += 4) {
             const float4 a = *reinterpret_cast<const float4*>(&sh[ti * CAUSAL_PITCH + kk]);
             const float4 b = *reinterpret_cast<const float4*>(&sm[tj * CAUSAL_PITCH + kk]);
-            tot = fmaf(a.x, b.x, tot); tot = fmaf(a.y, b.y, tot); tot = fmaf(a.z, b.z, tot); tot = fmaf(a.w, b.w, tot);
+            t0 = fmaf(a.x, b.x, t0); t1 = fmaf(a.y, b.y, t1); t2 = fmaf(a.z, b.z, t2); t3 = fmaf(a.w, b.w, t3);
         }
         __syncthreads();
     }
-    return tot;
+    return (t0 + t1) + (t2 + t3);
 }
 
 // ---- stacked-Gram MFMA path (cost_mfma.hip) -------------------------------------------------
@@ -90,6 +99,7 @@ struct GramPlan {
     int nchunk;
     size_t gpart_bytes;   // [nchunk][GRAM_NSUB][1024] float
     size_t gsum_bytes;    // [GRAM_REDUCE_SPLIT][GRAM_NSUB*1024] double
+    size_t caus_bytes;    // [3][GRAM_ROWS][GRAM_ROWS] float: causal sums
     size_t ws_bytes;
 };
 

@@ -450,9 +450,37 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
 // consecutive Gram entries (one 256-byte line per chunk): thread (e = t & 63, grp = t >> 6) adds
 // chunks grp, grp+16, ... in increasing order, then the 16 group sums are combined in fixed order
 // through LDS -> run-to-run deterministic.
+//
+// The causal terms of the cost (gan_utils.py:37-46) do not depend on the Gram sums, so they are
+// computed here as well, by extra workgroups of the same launch (blockIdx >= GRAM_ELEMS/64): the
+// first four waves of each compute one 16x16 output tile (the dot products are LDS-bandwidth bound,
+// so one tile per CU; the other waves retire at once), results to `caus` [slot][B1][B2].
+// gram_finalize then only gathers and adds -- its dependent chain (launch -> Gram gathers -> feature
+// loads -> LDS dot products) was as long as the whole reduction.
+struct CausalPre {
+    const float* h[3];   // per slot: rows; null = slot unused
+    const float* M[3];   // per slot: columns
+    float* caus;         // [3][B1][B2]
+    int B1, B2, T, J, nti, ntj;
+};
+
 __global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gpart, int nchunk, unsigned mask,
-                                                    double* __restrict__ gsum) {
+                                                    double* __restrict__ gsum, CausalPre cp) {
     __shared__ double part[16][64];
+    __shared__ __attribute__((aligned(16))) float csh[CAUSAL_TILE * CAUSAL_PITCH];
+    __shared__ __attribute__((aligned(16))) float csm[CAUSAL_TILE * CAUSAL_PITCH];
+    if (blockIdx.x >= GRAM_ELEMS / 64) {
+        if (threadIdx.x >= 256) return;                      // whole waves; barriers below count the live ones
+        const int tile = blockIdx.x - GRAM_ELEMS / 64;
+        const int per = cp.nti * cp.ntj;
+        const int slot = tile / per, rem = tile % per;
+        if (slot >= 3 || cp.h[slot] == nullptr) return;      // block-uniform
+        const int i0 = (rem / cp.ntj) * CAUSAL_TILE, j0 = (rem % cp.ntj) * CAUSAL_TILE;
+        const float v = causal_tile16(cp.h[slot], cp.M[slot], i0, j0, cp.B1, cp.B2, cp.T, cp.J, csh, csm);
+        const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
+        if (i < cp.B1 && j < cp.B2) cp.caus[((int64_t)slot * cp.B1 + i) * cp.B2 + j] = v;
+        return;
+    }
     const int t = threadIdx.x, el = t & 63, grp = t >> 6;
     const int e = blockIdx.x * 64 + el;
     const int sub = e >> 10;
@@ -493,8 +521,9 @@ struct GramFin {
     float* out[3];
     const float* h[3];   // causal term per output (rows), or null
     const float* M[3];
-    const float* h2;     // bi-causal second term (GRAM_XY only)
+    const float* h2;     // bi-causal second term (GRAM_XY / GRAM_SAME only)
     const float* M2;
+    const float* caus;   // [3][B1][B2] causal sums written by gram_reduce's extra workgroups: slot p for h[p]; slot 1 for h2
     float sc;
     int T, J;
 };
@@ -508,8 +537,6 @@ __device__ __forceinline__ double gram_at(const double* __restrict__ gsum, int s
 
 // One 16x16 output tile per block: distances from the summed Gram entries (fp64), scale, causal term.
 __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
-    __shared__ __attribute__((aligned(16))) float sh[CAUSAL_TILE * CAUSAL_PITCH];
-    __shared__ __attribute__((aligned(16))) float sm[CAUSAL_TILE * CAUSAL_PITCH];
     const int p = blockIdx.z;
     const int i0 = blockIdx.y * CAUSAL_TILE, j0 = blockIdx.x * CAUSAL_TILE;
     const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
@@ -517,6 +544,9 @@ __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
     const double* G = f.gsum;
     // all Gram entries are fetched up front (no control flow between the loads: one memory round trip)
     const int ii = ok ? i : 0, jj = ok ? j : 0;
+    const int64_t plane = (int64_t)f.B1 * f.B2, at = (int64_t)ii * f.B2 + jj;
+    const float ca = f.h[p] ? f.caus[p * plane + at] : 0.f;
+    const float cb = (p == 0 && f.h2) ? f.caus[plane + at] : 0.f;
     double D;
     if (f.mode == GRAM_LOSS3) {
         const double g_ii = gram_at(G, ii, ii), g_jj = gram_at(G, jj, jj), g_ij = gram_at(G, ii, jj);
@@ -537,8 +567,8 @@ __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
     }
     if (D < 0.0) D = 0.0;   // a squared distance; rounding of the Gram terms may leave -tiny
     float c = (float)D * f.sc;
-    if (f.h[p]) c += causal_tile16(f.h[p], f.M[p], i0, j0, f.B1, f.B2, f.T, f.J, sh, sm) * f.sc;
-    if (p == 0 && f.h2) c += causal_tile16(f.h2, f.M2, i0, j0, f.B1, f.B2, f.T, f.J, sh, sm) * f.sc;
+    if (f.h[p]) c += ca * f.sc;
+    if (p == 0 && f.h2) c += cb * f.sc;
     if (ok) f.out[p][(int64_t)i * f.B2 + j] = c;
 }
 
@@ -589,7 +619,8 @@ GramPlan plan_gram(int64_t K) {
     if (max_chunks < pl.nchunk) max_chunks = pl.nchunk;
     pl.gpart_bytes = align_up((size_t)max_chunks * GRAM_SLABS * 1024 * sizeof(float), 256);
     pl.gsum_bytes = align_up((size_t)GRAM_ELEMS * sizeof(double), 256);
-    pl.ws_bytes = pl.gpart_bytes + pl.gsum_bytes;
+    pl.caus_bytes = align_up((size_t)3 * GRAM_ROWS * GRAM_ROWS * sizeof(float), 256);
+    pl.ws_bytes = pl.gpart_bytes + pl.gsum_bytes + pl.caus_bytes;
     return pl;
 }
 
@@ -648,11 +679,23 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     else hipLaunchKernelGGL(gram128_partial<false>, dim3(pl.nchunk), dim3(256), 0, st, ga);
     int rc = launch_status("gram128_partial");
     if (rc || partial_only) return rc;
-    hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 64), dim3(1024), 0, st,
-                       (const float*)ga.gpart, pl.nchunk, ga.mask, gsum);
+    CausalPre cp{};
+    cp.caus = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.gpart_bytes + pl.gsum_bytes);
+    cp.B1 = gf.B1; cp.B2 = gf.B2; cp.T = T; cp.J = J;
+    cp.nti = (gf.B1 + CAUSAL_TILE - 1) / CAUSAL_TILE; cp.ntj = (gf.B2 + CAUSAL_TILE - 1) / CAUSAL_TILE;
+    int nslot = 0;
+    if (loss3) {
+        for (int p = 0; p < 3; ++p) { cp.h[p] = gf.h[p]; cp.M[p] = gf.M[p]; if (gf.h[p]) nslot = p + 1; }
+    } else {
+        cp.h[0] = gf.h[0]; cp.M[0] = gf.M[0]; cp.h[1] = gf.h2; cp.M[1] = gf.M2;
+        nslot = gf.h2 ? 2 : (gf.h[0] ? 1 : 0);
+    }
+    const int ncausal = nslot * cp.nti * cp.ntj;
+    hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 64 + ncausal), dim3(1024), 0, st,
+                       (const float*)ga.gpart, pl.nchunk, ga.mask, gsum, cp);
     rc = launch_status("gram_reduce");
     if (rc) return rc;
-    gf.gsum = gsum; gf.mode = mode; gf.sc = sc; gf.T = T; gf.J = J;
+    gf.gsum = gsum; gf.caus = cp.caus; gf.mode = mode; gf.sc = sc; gf.T = T; gf.J = J;
     hipLaunchKernelGGL(gram_finalize, dim3((gf.B2 + CAUSAL_TILE - 1) / CAUSAL_TILE, (gf.B1 + CAUSAL_TILE - 1) / CAUSAL_TILE, nout),
                        dim3(256), 0, st, gf);
     return launch_status("gram_finalize");

@@ -549,12 +549,15 @@ __global__ void mixed_divergence_bwd(const float* __restrict__ gloss, float* __r
 // ------------------------------------------------------------------------------------------
 struct SinkGeom { int lpr, ept, threads; };
 
-static SinkGeom sink_geom(int n) {
+static SinkGeom sink_geom(int n, bool forward) {
     SinkGeom g;
-    // n*lpr <= 1024.  Measured at n = 64 (stamped diagnostic build, tools/diag_sinkhorn.py): a
-    // half-step is a dependent chain of ~110 VALU instructions per wave, so more waves per SIMD
-    // (16 lanes per line = 1024 threads) hide more of it than fewer, longer threads.
-    g.lpr = (n <= 64) ? 16 : 8;
+    // n*lpr <= 1024.  Every wave of the workgroup runs the same instruction stream between two
+    // barriers, four waves take turns on each SIMD at 1024 threads, and the per-wave overhead (DPP
+    // reduction steps, log, stores) does not shrink with the number of entries per lane.  Measured
+    // at n = 64 over 100 iterations (tools/bench_sinkhorn.py, tools/ab_sk.sh): forward 8 lanes per
+    // line 72 us, 16: 82 us, 4: slower still; the reverse sweep is within 2 us between 8 and 16
+    // (72 us) and keeps 16.
+    g.lpr = (n <= 32) ? 16 : (n <= 64 ? (forward ? 8 : 16) : 8);
     if (n > 32 && n <= 64) {
         // tuning knob for the configs[1] size: 4, 8 or 16 lanes per line (256 / 512 / 1024 threads)
         const char* e = getenv("KCCOT_SK_LPR");
@@ -629,7 +632,7 @@ extern "C" int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float ep
     if (n > SK_MAXN)
         return launch_sinkhorn_fwd_gen(C, nprob, n, eps, L, Lmin, thresh, stop_mode, u_hist, v_hist, cost_out, nits_out,
                                        pi_out, ws, ws_bytes, (hipStream_t)stream);
-    SinkGeom g = sink_geom(n);
+    SinkGeom g = sink_geom(n, true);
     SinkArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
                nullptr, g_div_loss, g_div_ticket, sink_shortcut_enabled()};
 #ifdef KCCOT_DIAG
@@ -655,7 +658,7 @@ extern "C" int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const
     if (n > SK_MAXN)
         return launch_sinkhorn_bwd_gen(C, u_hist, v_hist, nits, nprob, n, eps, L, gcost, dC_out, ws, ws_bytes,
                                        (hipStream_t)stream);
-    SinkGeom g = sink_geom(n);
+    SinkGeom g = sink_geom(n, false);
     SinkBwdArgs a{C, u_hist, v_hist, nits, gcost, dC_out, n, L, eps, (float)(1.0 / (double)eps), g_div_weights};
     hipStream_t st = (hipStream_t)stream;
     KCCOT_SK_DISPATCH(sinkhorn_bwd_reg, a, g, nprob, st)

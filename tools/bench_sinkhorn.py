@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Kernel-only timing of the Sinkhorn forward / reverse sweep at configs[1] size (three 64x64 problems).
+usage: bench_sinkhorn.py [near|far] ; env knobs: KCCOT_SK_NO_SHORTCUT, KCCOT_SK_BWD_EXACT, KCCOT_SK_LPR"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from kccotgan_amd._lib import lib, ptr
+regime = sys.argv[1] if len(sys.argv) > 1 else "near"
+g = np.load(os.path.join(ROOT, "tests", "golden", "cfg2_s0_near.npz" if regime == "near" else "cfg2_s1_far.npz"))
+C = torch.from_numpy(np.stack([g["C_xy"], g["C_xx"], g["C_yy"]])).cuda().contiguous()
+n, L = C.shape[1], 100
+uh = torch.empty(3, L, n, device="cuda"); vh = torch.empty(3, L, n, device="cuda")
+cost = torch.empty(3, device="cuda"); nits = torch.zeros(6, dtype=torch.int32, device="cuda")
+gc = torch.tensor([2.0, -1.0, -1.0], device="cuda"); dC = torch.empty_like(C)
+def fwd(): assert lib.kccot_sinkhorn_fwd_f32(ptr(C), 3, n, 1.0, L, 100, 1e-2, 0, ptr(uh), ptr(vh), ptr(cost), ptr(nits), None, None, 0, None) == 0
+def bwd(): assert lib.kccot_sinkhorn_bwd_f32(ptr(C), ptr(uh), ptr(vh), ptr(nits), 3, n, 1.0, L, ptr(gc), ptr(dC), None, 0, None) == 0
+def timeit(f, reps=200):
+    for _ in range(10): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+tf = timeit(fwd); tb = timeit(bwd)
+ref = None
+if os.environ.get("KCCOT_SK_BWD_EXACT") != "1":
+    os.environ["KCCOT_SK_BWD_EXACT"] = "1"; d1 = dC.clone(); bwd(); torch.cuda.synchronize()
+    ref = float((d1 - dC).abs().max() / dC.abs().max())
+print("%s: fwd %.1f us  bwd %.1f us  nits %s  cost %s  scaling-vs-exact rel diff %s" % (regime, tf, tb, nits.tolist(), [round(c, 4) for c in cost.tolist()], ref))
