@@ -255,7 +255,7 @@ def main():
             # exact three-way bf16 split on the bf16 MFMA pipe: 6 x 10 sub-tiles x 2*32*32*K flops = 15.1 GFLOP,
             # ideal 6.0 us at the 2.5 PFLOP/s dense bf16 peak vs 7.9 us of HBM -> HBM-bound
             exec_flops = 6 * 10 * 2 * 32 * 32 * K
-            roof = {"kernel": "gram128_partial_x3", "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"kernel": "gram128_partial_x3ws", "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hbm / HBM_PEAK_GBS, "executed_bf16_mfma_tflops": exec_flops / t_s / 1e12,
                     "bf16_mfma_frac": exec_flops / t_s / 1e12 / 2500.0}
         roof.update({"traffic": traffic, "kernel_us": kt["partial"], "cost_stage_us": kt["stage"],

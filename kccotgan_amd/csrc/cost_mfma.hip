@@ -352,6 +352,84 @@ __global__ __launch_bounds__(256) void gram128_partial_x3(GramArgs ga) {
     }
 }
 
+// ---- consumer side of the wave-specialised kernel -------------------------------------------------
+// One ds_read_b128 moves 1 KB = 8 cycles of the CU's LDS port, one bf16 MFMA keeps a SIMD's matrix
+// pipe busy for 32 cycles and four consumer waves run concurrently: at one fragment read per MFMA
+// (six reads for the six products of a sub-tile, as the single-role kernels do) the LDS port is
+// saturated before the matrix pipes are.  So the 10 sub-tiles (+ 2 half sub-tiles, for balance:
+// 2.5 sub-tiles of MFMA work per SIMD) are dealt to the waves such that the three sub-tiles of a
+// wave SHARE row blocks and every fragment triple (h, m, l) is read once per 16-k step and used by
+// every product that needs it -- 30 reads for 60 MFMAs instead of 60:
+//     wave W owns row block X = W and its diagonal sub-tile (X,X) (A and B fragments coincide),
+//     an off-diagonal sub-tile with block Y, and one k-half of a sub-tile that pairs X or Y with Z:
+//        W   X  Y  Z   sub-tiles                     slabs
+//        0   0  1  2   (0,0) (0,1) (0,2) k-half 0    0, 1, 2
+//        1   1  2  0   (1,1) (1,2) (0,2) k-half 1    4, 5, 10
+//        2   2  3  1   (2,2) (2,3) (1,3) k-half 0    7, 8, 6
+//        3   3  0  1   (3,3) (0,3) (1,3) k-half 1    9, 3, 11
+// (split sub-tiles 2 and 6 keep their second k-half in slabs 10 and 11: GRAM_SPLIT_26 in gram_reduce).
+struct Frag3 { bf16x8 h, m, l; };
+
+__device__ __forceinline__ Frag3 ld_frag3(const unsigned char* zs, int off) {
+    Frag3 f;
+    f.h = *reinterpret_cast<const bf16x8*>(zs + off);
+    f.m = *reinterpret_cast<const bf16x8*>(zs + XPLANE + off);
+    f.l = *reinterpret_cast<const bf16x8*>(zs + 2 * XPLANE + off);
+    return f;
+}
+
+// acc += A * B^T with the exact three-way split: hh + (hm + mh) + (hl + lh + mm), smallest terms first
+__device__ __forceinline__ void mfma_x3(f32x16& acc, const Frag3& A, const Frag3& B) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void store_tile(float* base, int slab, int lane, const f32x16& acc) {
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    float* o = base + slab * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc[r];
+}
+
+template <int W>
+__device__ __forceinline__ void x3ws_consume(const unsigned char* zsA, const unsigned char* zsB, int nstage, int lane,
+                                             float* base) {
+    constexpr int X = W, Y = (W + 1) & 3, Z = (W == 0) ? 2 : (W == 1 ? 0 : 1);
+    constexpr int KB0 = (W & 1) * 2;                           // the k-half of the stage this wave takes of its split sub-tile
+    constexpr int SLAB1 = (W == 0) ? 0 : (W == 1 ? 4 : (W == 2 ? 7 : 9));
+    constexpr int SLAB2 = (W == 0) ? 1 : (W == 1 ? 5 : (W == 2 ? 8 : 3));
+    constexpr int SLAB3 = (W == 0) ? 2 : (W == 1 ? 10 : (W == 2 ? 6 : 11));
+    const int lo = (lane & 31) * XPITCH + 16 * (lane >> 5);    // row (lane&31), k half (lane>>5) of a 16-k block
+    const int ox = X * 32 * XPITCH + lo, oy = Y * 32 * XPITCH + lo, oz = Z * 32 * XPITCH + lo;
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+    __syncthreads();                                  // stage 0 is in buffer A
+    for (int s = 0; s < nstage; ++s) {
+        const unsigned char* zs = (s & 1) ? zsB : zsA;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const Frag3 fx = ld_frag3(zs, ox + kb * 32), fy = ld_frag3(zs, oy + kb * 32);
+            mfma_x3(acc0, fx, fx);
+            if (W != 3) mfma_x3(acc1, fx, fy); else mfma_x3(acc1, fy, fx);      // (X,Y), or (0,3) = (Y,X) for W = 3
+            if (kb >= KB0 && kb < KB0 + 2) {
+                const Frag3 fz = ld_frag3(zs, oz + kb * 32);
+                if (W == 0) mfma_x3(acc2, fx, fz);          // (0,2)
+                else if (W == 3) mfma_x3(acc2, fz, fx);     // (1,3)
+                else mfma_x3(acc2, fz, fy);                 // (0,2) resp. (1,3)
+            }
+        }
+        __syncthreads();                              // stage s consumed; stage s+1 is complete
+    }
+    store_tile(base, SLAB1, lane, acc0);
+    store_tile(base, SLAB2, lane, acc1);
+    store_tile(base, SLAB3, lane, acc2);
+}
+
 // ------------------------------------------------------------------------------------------
 // Wave-specialised form of the x3 kernel: 8 waves per workgroup, two per SIMD.  Waves 0-3 are
 // PRODUCERS (global loads, E = src2 - src1, three-way split, ds_write into the next LDS buffer),
@@ -360,6 +438,7 @@ __global__ __launch_bounds__(256) void gram128_partial_x3(GramArgs ga) {
 // that share a SIMD run concurrently: the staging no longer sits between the MFMA phases of the
 // same wave.  One s_barrier per stage (every wave executes the same number of them).
 // ------------------------------------------------------------------------------------------
+template <bool gram_two_deep>
 __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
     __shared__ __attribute__((aligned(16))) unsigned char zsA[3 * XPLANE];
     __shared__ __attribute__((aligned(16))) unsigned char zsB[3 * XPLANE];
@@ -383,25 +462,51 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
             rp[j] = (j < 4 ? ga.src1 : ga.src2) + (int64_t)r * ga.K;
         }
         const int wbase = r0 * XPITCH + c4 * 2;
-        float4 v[8];
+        // gram_two_deep (KCCOT_GRAM_DEEP=1, off by default): two stages of loads in flight per producer
+        // thread (v: even stages, w: odd stages; each set is re-issued right after it has been consumed):
+        // 64 KB outstanding per CU instead of 32 KB.  Measured 22.1-22.6 us against 20.4-21.3 us for one
+        // stage in flight (tools/ab_gram.sh): the stream is not limited by bytes in flight.
+        float4 v[8], w[8];
+        const bool deep = gram_two_deep;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kbeg + c4, kend, ok[j]);
+        if (deep && nstage > 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = ld4(rp[j], kbeg + XKT + c4, kend, ok[j]);
+        }
         for (int s = 0; s <= nstage; ++s) {
             // stage s goes into buffer s&1 (the consumers read it during iteration s+1 of this loop)
             if (s < nstage) {
                 unsigned char* zb = (s & 1) ? zsB : zsA;
+                if (!deep || (s & 1) == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (ga.pair_diff) {
-                        v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
+                    for (int j = 0; j < 4; ++j) {
+                        if (ga.pair_diff) {
+                            v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
+                        }
+                        split3_store(zb, wbase + 16 * j * XPITCH, v[j]);
+                        split3_store(zb, wbase + (64 + 16 * j) * XPITCH, v[j + 4]);
                     }
-                    split3_store(zb, wbase + 16 * j * XPITCH, v[j]);
-                    split3_store(zb, wbase + (64 + 16 * j) * XPITCH, v[j + 4]);
-                }
-                const int64_t kn = kbeg + (int64_t)(s + 1) * XKT;
-                if (s + 1 < nstage) {
+                    const int ahead = deep ? 2 : 1;
+                    if (s + ahead < nstage) {
+                        const int64_t kn = kbeg + (int64_t)(s + ahead) * XKT;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kn + c4, kend, ok[j]);
+                        for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kn + c4, kend, ok[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (ga.pair_diff) {
+                            w[j + 4].x -= w[j].x; w[j + 4].y -= w[j].y; w[j + 4].z -= w[j].z; w[j + 4].w -= w[j].w;
+                        }
+                        split3_store(zb, wbase + 16 * j * XPITCH, w[j]);
+                        split3_store(zb, wbase + (64 + 16 * j) * XPITCH, w[j + 4]);
+                    }
+                    if (s + 2 < nstage) {
+                        const int64_t kn = kbeg + (int64_t)(s + 2) * XKT;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) w[j] = ld4(rp[j], kn + c4, kend, ok[j]);
+                    }
                 }
             }
             __syncthreads();
@@ -410,40 +515,13 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
     }
 
     // ---------------------------------------------------------------------- consumers
-    const WaveWork ww = wave_work(0x3FFu, wave - 4);
-    const int lo = (lane & 31) * XPITCH + 16 * (lane >> 5);
-    const int a0 = ww.a[0] * 32 * XPITCH + lo, b0 = ww.b[0] * 32 * XPITCH + lo;
-    const int a1 = ww.a[1] * 32 * XPITCH + lo, b1 = ww.b[1] * 32 * XPITCH + lo;
-    const int a2 = ww.a[2] * 32 * XPITCH + lo, b2 = ww.b[2] * 32 * XPITCH + lo;
-    const int half = ((wave - 4) & 1) * 2;
-    f32x16 acc0, acc1, acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
-    __syncthreads();                                  // stage 0 is in buffer A
-    for (int s = 0; s < nstage; ++s) {
-        const unsigned char* zs = (s & 1) ? zsB : zsA;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            KCCOT_X3(acc0, a0 + kb * 32, b0 + kb * 32)
-            KCCOT_X3(acc1, a1 + kb * 32, b1 + kb * 32)
-        }
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            KCCOT_X3(acc2, a2 + (half + g) * 32, b2 + (half + g) * 32)
-        }
-        __syncthreads();                              // stage s consumed; stage s+1 is complete
-    }
     float* base = ga.gpart + (int64_t)blockIdx.x * GRAM_SLABS * 1024;
-    const int col = lane & 31, rbase = 4 * (lane >> 5);
-    float* o = base + ww.slab[0] * 1024;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc0[r];
-    o = base + ww.slab[1] * 1024;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc1[r];
-    o = base + ww.slab[2] * 1024;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc2[r];
+    switch (wave - 4) {
+        case 0: x3ws_consume<0>(zsA, zsB, nstage, lane, base); break;
+        case 1: x3ws_consume<1>(zsA, zsB, nstage, lane, base); break;
+        case 2: x3ws_consume<2>(zsA, zsB, nstage, lane, base); break;
+        default: x3ws_consume<3>(zsA, zsB, nstage, lane, base); break;
+    }
 }
 
 // Sum the per-chunk partial Gram sub-tiles in fp64.  One workgroup of 1024 threads owns 64
@@ -464,7 +542,9 @@ struct CausalPre {
     int B1, B2, T, J, nti, ntj;
 };
 
-__global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gpart, int nchunk, unsigned mask,
+enum { GRAM_SPLIT_NONE = 0, GRAM_SPLIT_89 = 1, GRAM_SPLIT_26 = 2 };
+
+__global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gpart, int nchunk, unsigned mask, int split_mode,
                                                     double* __restrict__ gsum, CausalPre cp) {
     __shared__ double part[16][64];
     __shared__ __attribute__((aligned(16))) float csh[CAUSAL_TILE * CAUSAL_PITCH];
@@ -485,7 +565,11 @@ __global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gp
     const int e = blockIdx.x * 64 + el;
     const int sub = e >> 10;
     const bool need = (mask >> sub) & 1u;
-    const bool split = (mask == 0x3FFu) && sub >= 8;   // second k-half lives in slab sub+2
+    // sub-tiles whose k-groups are shared by two waves keep the second half in slab 10 / 11
+    const int second = (split_mode == GRAM_SPLIT_89 && sub >= 8) ? sub + 2
+                     : (split_mode == GRAM_SPLIT_26 && (sub == 2 || sub == 6)) ? (sub == 2 ? 10 : 11) : -1;
+    const bool split = second >= 0;
+    const int soff = split ? (second - sub) * 1024 : 0;
     double s = 0.0;
     if (need) {
         const float* p = gpart + e;
@@ -495,13 +579,13 @@ __global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gp
         for (; c + 48 < nchunk; c += 64) {
             const float a0 = p[c * cs], a1 = p[(c + 16) * cs], a2 = p[(c + 32) * cs], a3 = p[(c + 48) * cs];
             float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-            if (split) { b0 = p[c * cs + 2048]; b1 = p[(c + 16) * cs + 2048]; b2 = p[(c + 32) * cs + 2048]; b3 = p[(c + 48) * cs + 2048]; }
+            if (split) { b0 = p[c * cs + soff]; b1 = p[(c + 16) * cs + soff]; b2 = p[(c + 32) * cs + soff]; b3 = p[(c + 48) * cs + soff]; }
             s += (double)a0; s += (double)b0; s += (double)a1; s += (double)b1;
             s += (double)a2; s += (double)b2; s += (double)a3; s += (double)b3;
         }
         for (; c < nchunk; c += 16) {
             s += (double)p[c * cs];
-            if (split) s += (double)p[c * cs + 2048];
+            if (split) s += (double)p[c * cs + soff];
         }
     }
     part[grp][el] = s;
@@ -670,10 +754,16 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     ga.K = K; ga.chunk = pl.chunk;
     ga.gpart = static_cast<float*>(ws);
     double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.gpart_bytes);
+    int split_mode = (ga.mask == 0x3FFu) ? GRAM_SPLIT_89 : GRAM_SPLIT_NONE;
     if (ga.mask == 0x3FFu && gram_use_x3()) {
         const char* e = getenv("KCCOT_GRAM_WS");   // =0: the single-role x3 kernel (A/B)
         if (e && atoi(e) == 0) hipLaunchKernelGGL(gram128_partial_x3, dim3(pl.nchunk), dim3(256), 0, st, ga);
-        else hipLaunchKernelGGL(gram128_partial_x3ws, dim3(pl.nchunk), dim3(512), 0, st, ga);
+        else {
+            const char* d = getenv("KCCOT_GRAM_DEEP");   // =1: two stages of loads in flight (A/B: measured 1-2 us SLOWER)
+            if (d && atoi(d) == 1) hipLaunchKernelGGL(gram128_partial_x3ws<true>, dim3(pl.nchunk), dim3(512), 0, st, ga);
+            else hipLaunchKernelGGL(gram128_partial_x3ws<false>, dim3(pl.nchunk), dim3(512), 0, st, ga);
+            split_mode = GRAM_SPLIT_26;
+        }
     }
     else if (ga.mask == 0x3FFu) hipLaunchKernelGGL(gram128_partial<true>, dim3(pl.nchunk), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL(gram128_partial<false>, dim3(pl.nchunk), dim3(256), 0, st, ga);
@@ -692,7 +782,7 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     }
     const int ncausal = nslot * cp.nti * cp.ntj;
     hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 64 + ncausal), dim3(1024), 0, st,
-                       (const float*)ga.gpart, pl.nchunk, ga.mask, gsum, cp);
+                       (const float*)ga.gpart, pl.nchunk, ga.mask, split_mode, gsum, cp);
     rc = launch_status("gram_reduce");
     if (rc) return rc;
     gf.gsum = gsum; gf.caus = cp.caus; gf.mode = mode; gf.sc = sc; gf.T = T; gf.J = J;
