@@ -13,6 +13,7 @@
 #include <math.h>
 #include <float.h>
 #include <stdlib.h>
+#include <stdint.h>
 
 namespace kccot {
 
@@ -330,11 +331,273 @@ __global__ __launch_bounds__(NT) void smooth_plane(PlaneArgs a) {
     }
 }
 
+// ---- smoothing along a strided axis as a pure stream ----------------------------------------------
+// Along T (stride W*C) and H (stride T*W*C) a thread can own a short contiguous piece (VW floats) of
+// one line of the axis, issue the loads of all L <= LMAX steps of it at once (L x 4 VW bytes in
+// flight per thread: a stream, not a latency chain) and walk the axis with a (2R+1)-deep register
+// window -- no LDS, no barrier, consecutive lanes on consecutive addresses at every step.
+// REFLECT borders: the head of the window is filled mirrored; near the end the incoming value
+// x[2(L-1)-(p+R)] is already inside the window (slot 2(L-1-p)).  Same fma order as the other kernels.
+// Everything is straight-line code on vector types (selects, no branches around the register arrays),
+// so the line stays in VGPRs; steps p >= L of the unrolled walk run on clamped copies and are dropped.
+//   WALK_MAX   forward, per-workgroup maxima only          WALK_WRITE  forward, writes s / max
+//   WALK_RAW   forward, writes s                            WALK_ADJ    adjoint of WALK_RAW
+//   WALK_ADJX  adjoint preceded by the max-normalisation adjoint  x = g / max - corr * [out == 1]
+// Adjoint weights: w_k(p) = w[k] + [p >= 1] w[-2p-k] + [p <= L-2] w[2(L-1)-2p-k] (taps outside -R..R
+// are zero), sources outside [0,L) do not exist; the head fold is known at compile time, the tail
+// fold depends on d = L-1-p and is chosen with scalar selects.
+enum { WALK_MAX = 0, WALK_WRITE = 1, WALK_RAW = 2, WALK_ADJ = 3, WALK_ADJX = 4 };
+
+struct WalkArgs {
+    const float* in;       // forward: input; adjoint: incoming gradient
+    const float* out_fwd;  // WALK_ADJX: the forward's normalised output
+    float* out;
+    float* blockmax;       // WALK_MAX
+    const float* mx;       // WALK_WRITE / WALK_ADJX: device scalar, the tensor maximum
+    const float* res;      // WALK_ADJX: {sum gout*out, #ties}
+    int L;                 // axis length
+    int64_t S;             // axis stride in floats
+    int64_t inner;         // S / VW pieces per axis-stride block
+    int64_t ncols;         // pieces in total = numel / L / VW
+    Taps tp;
+};
+
+template <int VW> struct WalkVec { typedef float type __attribute__((ext_vector_type(VW))); };
+template <> struct WalkVec<1> { typedef float type; };
+
+template <int VW, typename V> __device__ __forceinline__ float& vat(V& v, int c) {
+    if constexpr (VW == 1) return v; else return reinterpret_cast<float*>(&v)[c];
+}
+
+template <int R, int LMAX, int VW, int MODE>
+__global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
+    typedef typename WalkVec<VW>::type V;
+    constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX;
+    __shared__ float red[16];
+    const int L = a.L;
+    const int64_t S = a.S;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = gid < a.ncols;
+    const int64_t g = ok ? gid : 0;
+    const int64_t off = (g / a.inner) * L * S + (g % a.inner) * VW;
+    const float* src = a.in + off;
+    float m = 1.f, corr = 0.f;
+    if (MODE == WALK_WRITE || MODE == WALK_ADJX) m = a.mx[0];
+    if (MODE == WALK_ADJX) corr = a.res[1] > 0.f ? a.res[0] / (m * a.res[1]) : 0.f;
+    V x[LMAX];
+#pragma unroll
+    for (int p = 0; p < LMAX; ++p) {    // addresses clamped, never predicated: all loads issue back to back
+        const int64_t o = (int64_t)(p < L ? p : L - 1) * S;
+        x[p] = *reinterpret_cast<const V*>(src + o);
+        if (MODE == WALK_ADJX) {
+            V of = *reinterpret_cast<const V*>(a.out_fwd + off + o);
+#pragma unroll
+            for (int c = 0; c < VW; ++c) vat<VW>(x[p], c) = vat<VW>(x[p], c) / m - (vat<VW>(of, c) == 1.0f ? corr : 0.f);
+        }
+    }
+    V zero;
+#pragma unroll
+    for (int c = 0; c < VW; ++c) vat<VW>(zero, c) = 0.f;
+    V win[2 * R + 1];                   // win[j] = x at position p - R + j
+#pragma unroll
+    for (int j = 0; j <= 2 * R; ++j) {
+        if (!ADJ) win[j] = x[j < R ? R - j : j - R];                       // mirrored head
+        else win[j] = (j < R) ? zero : ((j - R < L) ? x[j - R] : zero);    // nothing before 0 / after L-1
+    }
+    float vmax = -FLT_MAX;
+#pragma unroll
+    for (int p = 0; p < LMAX; ++p) {
+        const bool live = p < L;        // uniform
+        const int d = L - 1 - p;        // distance to the last position (uniform)
+        V acc = zero;
+#pragma unroll
+        for (int k = -R; k <= R; ++k) {
+            float w = a.tp.w[k + R];
+            if (ADJ) {
+                const int hf = -2 * p - k;                       // head fold: compile-time
+                if (p >= 1 && hf >= -R && hf <= R) w += a.tp.w[hf + R];
+                float tf = 0.f;                                  // tail fold: 2d - k in [-R, R], d >= 1
+#pragma unroll
+                for (int dd = 1; dd <= R; ++dd)
+                    if (2 * dd - k >= -R && 2 * dd - k <= R) tf = (d == dd) ? a.tp.w[2 * dd - k + R] : tf;
+                w += tf;
+            }
+            if constexpr (VW == 1) acc = fmaf(w, win[k + R], acc);
+            else {
+                V wv;
+#pragma unroll
+                for (int c = 0; c < VW; ++c) vat<VW>(wv, c) = w;
+                acc = __builtin_elementwise_fma(wv, win[k + R], acc);
+            }
+        }
+        if (MODE == WALK_MAX) {
+            float mx = vat<VW>(acc, 0);
+#pragma unroll
+            for (int c = 1; c < VW; ++c) mx = fmaxf(mx, vat<VW>(acc, c));
+            vmax = live ? fmaxf(vmax, mx) : vmax;
+        } else {
+            if (MODE == WALK_WRITE) {
+#pragma unroll
+                for (int c = 0; c < VW; ++c) vat<VW>(acc, c) = vat<VW>(acc, c) / m;
+            }
+            if (ok && live) *reinterpret_cast<V*>(a.out + off + (int64_t)p * S) = acc;
+        }
+        // advance to p + 1: the incoming position is p + 1 + R
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) win[j] = win[j + 1];
+        V inc;
+        if (!ADJ) {
+            // past the end the mirror image x[2(L-1) - (p+1+R)] is in slot 2(d-1), d - 1 < R
+            inc = win[0];
+            inc = d - 1 >= 1 ? win[2] : inc;
+            inc = d - 1 >= 2 ? win[4] : inc;
+            if (R > 3) inc = d - 1 >= 3 ? win[6] : inc;
+        } else {
+            inc = zero;
+        }
+        if (p + 1 + R < LMAX) inc = (p + 1 + R < L) ? x[p + 1 + R < LMAX ? p + 1 + R : 0] : inc;
+        win[2 * R] = inc;
+    }
+    if (MODE == WALK_MAX && a.blockmax) {
+        const float bm = block_max(ok ? vmax : -FLT_MAX, red);
+        if (threadIdx.x == 0) a.blockmax[blockIdx.x] = bm;
+    }
+}
+
+// ---- W axis, C == 1: the axis is the contiguous one ------------------------------------------------
+// A thread owns one 16-byte piece (4 consecutive w) of a row and reads its own, its left and its
+// right piece straight from global memory (the neighbours' loads are the same lines 16 bytes off:
+// L1 serves them, HBM sees every byte once); the 4 + 2R values it needs are then in registers.
+// REFLECT at the row ends needs no extra load: x[-j] = x[j] and x[W-1+j] = x[W-1-j] lie in the own
+// piece (j <= 3) or in the right / left neighbour (j = 4).  Raw sums only (the W stage of the 3-D
+// smoothing is never the last one).  Adjoint: sources outside the row are zero and the weights of
+// the first / last R+1 positions carry the fold-ins; they come from a per-position table in LDS so
+// that every lane runs the same code.
+template <int R, bool ADJ>
+__global__ __launch_bounds__(256) void smooth_w1(const float* __restrict__ in, float* __restrict__ out, int64_t npieces,
+                                                 int W, Taps tp) {
+    __shared__ float wt[ADJ ? 128 * (2 * R + 1) : 1];
+    if (ADJ) {
+        for (int e = threadIdx.x; e < W * (2 * R + 1); e += 256) {
+            const int p = e / (2 * R + 1), k = e % (2 * R + 1) - R;
+            int src; float w;
+            wt[e] = tap<R, true>(tp, p, k, W, src, w) ? w : 0.f;
+        }
+        __syncthreads();
+    }
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npieces) return;
+    const int W4 = W >> 2;
+    const int pc = (int)(gid % W4), w0 = pc * 4;
+    const float* row = in + (gid - pc) * 4;
+    const float4 own = *reinterpret_cast<const float4*>(row + w0);
+    const float4 lf = *reinterpret_cast<const float4*>(row + (pc > 0 ? w0 - 4 : w0));
+    const float4 rt = *reinterpret_cast<const float4*>(row + (pc < W4 - 1 ? w0 + 4 : w0));
+    // v[i] = x[w0 - 4 + i], i = 0..11
+    float v[12] = {lf.x, lf.y, lf.z, lf.w, own.x, own.y, own.z, own.w, rt.x, rt.y, rt.z, rt.w};
+    const bool first = pc == 0, last = pc == W4 - 1;
+    if (!ADJ) {
+        // mirrored values: x[-j] = x[j] (j = 1..4), x[W-1+j] = x[W-1-j]
+        const float m4 = rt.x, m4b = lf.w;               // x[4] resp. x[W-5] as seen from the first / last piece
+        v[3] = first ? own.y : v[3]; v[2] = first ? own.z : v[2]; v[1] = first ? own.w : v[1]; v[0] = first ? m4 : v[0];
+        v[8] = last ? own.z : v[8]; v[9] = last ? own.y : v[9]; v[10] = last ? own.x : v[10]; v[11] = last ? m4b : v[11];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = first ? 0.f : v[i]; v[8 + i] = last ? 0.f : v[8 + i]; }
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = -R; k <= R; ++k) {
+            const float w = ADJ ? wt[(w0 + j) * (2 * R + 1) + k + R] : tp.w[k + R];
+            acc = fmaf(w, v[4 + j + k], acc);
+        }
+        o[j] = acc;
+    }
+    *reinterpret_cast<float4*>(out + gid * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+static bool w1_eligible(int W, int C, int radius, const void* a, const void* b) {
+    return C == 1 && (radius == 3 || radius == 4) && W % 4 == 0 && W >= 8 && W <= 128 &&
+           (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0;
+}
+
+static int launch_w1(const float* in, float* out, int64_t n, int W, int radius, bool adjoint, const Taps& tp, hipStream_t st) {
+    const int64_t np = n / 4;
+    const dim3 grid((unsigned)((np + 255) / 256));
+    if (radius == 3) {
+        if (adjoint) hipLaunchKernelGGL((smooth_w1<3, true>), grid, dim3(256), 0, st, in, out, np, W, tp);
+        else hipLaunchKernelGGL((smooth_w1<3, false>), grid, dim3(256), 0, st, in, out, np, W, tp);
+    } else {
+        if (adjoint) hipLaunchKernelGGL((smooth_w1<4, true>), grid, dim3(256), 0, st, in, out, np, W, tp);
+        else hipLaunchKernelGGL((smooth_w1<4, false>), grid, dim3(256), 0, st, in, out, np, W, tp);
+    }
+    return launch_status("smooth_w1");
+}
+
+// vector width and unroll bound for an axis of length L whose lines are `S` floats apart; 0 = not eligible
+struct WalkPlan { int vw, lmax; };
+static WalkPlan walk_plan(int L, int64_t S, bool two_inputs, const void* p0, const void* p1, const void* p2) {
+    WalkPlan pl{0, 0};
+    if (L > 64) return pl;
+    pl.lmax = L <= 32 ? 32 : 64;
+    // registers: LMAX x VW floats for the line (twice that in flight while two tensors are being read)
+    int vw = (pl.lmax == 32) ? (two_inputs ? 2 : 4) : (two_inputs ? 1 : 2);
+    while (vw > 1 && (S % vw != 0 || (uintptr_t)p0 % (4 * vw) || (uintptr_t)p1 % (4 * vw) || (uintptr_t)p2 % (4 * vw))) vw >>= 1;
+    pl.vw = vw;
+    return pl;
+}
+
+template <int R, int MODE>
+static void launch_walk_r(const WalkArgs& wa, WalkPlan pl, hipStream_t st) {
+    const dim3 grid((unsigned)((wa.ncols + 255) / 256));
+#define KCCOT_WALK(LM, VW) hipLaunchKernelGGL((smooth_walk<R, LM, VW, MODE>), grid, dim3(256), 0, st, wa)
+    if (pl.lmax == 32) { if (pl.vw == 4) KCCOT_WALK(32, 4); else if (pl.vw == 2) KCCOT_WALK(32, 2); else KCCOT_WALK(32, 1); }
+    else { if (pl.vw == 2) KCCOT_WALK(64, 2); else KCCOT_WALK(64, 1); }
+#undef KCCOT_WALK
+}
+
+// one pass of the walk along an axis; `numel` = elements of the tensor
+static int launch_walk(int mode, WalkArgs wa, int radius, int64_t numel, WalkPlan pl, hipStream_t st) {
+    wa.inner = wa.S / pl.vw;
+    wa.ncols = numel / wa.L / pl.vw;
+#define KCCOT_WALK_MODE(M) do { if (radius == 3) launch_walk_r<3, M>(wa, pl, st); else launch_walk_r<4, M>(wa, pl, st); } while (0)
+    switch (mode) {
+        case WALK_MAX: KCCOT_WALK_MODE(WALK_MAX); break;
+        case WALK_WRITE: KCCOT_WALK_MODE(WALK_WRITE); break;
+        case WALK_RAW: KCCOT_WALK_MODE(WALK_RAW); break;
+        case WALK_ADJ: KCCOT_WALK_MODE(WALK_ADJ); break;
+        default: KCCOT_WALK_MODE(WALK_ADJX); break;
+    }
+#undef KCCOT_WALK_MODE
+    return launch_status("smooth_walk");
+}
+
+// sum(gout * out) and #(out == 1) with wide grid-stride loads (the per-element form above launches
+// n/256 workgroups of one element per thread)
+__global__ __launch_bounds__(256) void maxnorm_bwd_partial_v4(const float* __restrict__ gout, const float* __restrict__ out,
+                                                              int64_t n4, float* __restrict__ pdot, float* __restrict__ pcnt) {
+    __shared__ float red[16];
+    float d = 0.f, c = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        const float4 gg = reinterpret_cast<const float4*>(gout)[e];
+        const float4 oo = reinterpret_cast<const float4*>(out)[e];
+        d = fmaf(gg.x, oo.x, d); d = fmaf(gg.y, oo.y, d); d = fmaf(gg.z, oo.z, d); d = fmaf(gg.w, oo.w, d);
+        c += (oo.x == 1.0f ? 1.f : 0.f) + (oo.y == 1.0f ? 1.f : 0.f) + (oo.z == 1.0f ? 1.f : 0.f) + (oo.w == 1.0f ? 1.f : 0.f);
+    }
+    const float ds = block_sum(d, red);
+    const float cs = block_sum(c, red);
+    if (threadIdx.x == 0) { pdot[blockIdx.x] = ds; pcnt[blockIdx.x] = cs; }
+}
+
 static bool plane_eligible(int T, int W, int C, int radius, int naxes) {
     return naxes > 0 && (radius == 3 || radius == 4) && (int64_t)T * W * C <= 4096;
 }
 
 static int plane_hseg(int B, int H, bool halo) {
+    if (const char* e = getenv("KCCOT_SMOOTH_HSEG")) { const int v = atoi(e); if (v >= 1) return v; }   // tuning knob
     // >= 2 workgroups per CU; with an H stencil each segment re-reads 2R halo planes, so segments
     // stay as long as that allows
     for (int hs = halo ? 16 : 8; hs > 2; hs >>= 1)
@@ -413,6 +676,52 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
     if (ext && nodiv) return fail(KCCOT_EINVAL, "smooth_fwd: EXTERNAL_MAX and NO_DIVIDE are exclusive");
     if (na > 0 && in == out) return fail(KCCOT_EINVAL, "smooth_fwd: in-place convolution is not supported");
     const Taps tp = make_taps(sigma, radius);
+    const unsigned axes = flags & (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W);
+    const bool r34 = radius == 3 || radius == 4;
+    float* one = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)n * sizeof(float), 256) +
+                                          2 * align_up((size_t)nb * sizeof(float), 256));   // scalar slots: {1, 0, 0}
+    if (r34 && !nodiv && !getenv("KCCOT_SMOOTH_NO_STREAM") && (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W))) {
+        const int64_t WC = (int64_t)W * C;
+        const bool three = axes != KCCOT_SMOOTH_T;
+        // the last stage runs twice (maxima, then recompute + write s / max); earlier stages write raw sums
+        const WalkPlan pt = walk_plan(T, WC, false, in, out, three ? tmp : out);
+        const WalkPlan ph = three ? walk_plan(H, (int64_t)T * WC, false, tmp, out, out) : WalkPlan{1, 32};
+        const bool w1 = three && w1_eligible(W, C, radius, out, tmp);
+        if (pt.vw > 0 && ph.vw > 0 && (!three || w1 || plane_eligible(T, W, C, radius, 1))) {
+            WalkArgs wa{};
+            wa.tp = tp;
+            const float* last_in = in;
+            WalkPlan last = pt;
+            wa.L = T; wa.S = WC;
+            if (three) {
+                // T: in -> out (raw);  W: out -> tmp (raw, LDS plane kernel: the axis is contiguous);  H: tmp -> out
+                wa.in = in; wa.out = out;
+                if ((rc = launch_walk(WALK_RAW, wa, radius, n, pt, st))) return rc;
+                if (w1) {
+                    if ((rc = launch_w1(out, tmp, n, W, radius, false, tp, st))) return rc;
+                } else {
+                    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x3f800000, 1, st) != hipSuccess)
+                        return fail(KCCOT_EINVAL, "smooth_fwd: memset failed");
+                    PlaneArgs pa{};
+                    pa.in = out; pa.out = tmp; pa.mx = one; pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C;
+                    pa.axes = KCCOT_SMOOTH_W; pa.tp = tp; pa.hseg = plane_hseg(B, H, false);
+                    if ((rc = launch_plane(pa, radius, false, dim3((H + pa.hseg - 1) / pa.hseg, B), st))) return rc;
+                }
+                last_in = tmp; last = ph;
+                wa.L = H; wa.S = (int64_t)T * WC;
+            }
+            wa.in = last_in;
+            if (!ext) {
+                wa.out = nullptr; wa.blockmax = bmax;
+                if ((rc = launch_walk(WALK_MAX, wa, radius, n, last, st))) return rc;
+                const int64_t nblk = (n / wa.L / last.vw + 255) / 256;
+                hipLaunchKernelGGL(reduce_blockmax, dim3(1), dim3(1024), 0, st, (const float*)bmax, nblk, max_inout);
+                if ((rc = launch_status("reduce_blockmax"))) return rc;
+            }
+            wa.out = out; wa.blockmax = nullptr; wa.mx = max_inout;
+            return launch_walk(WALK_WRITE, wa, radius, n, last, st);
+        }
+    }
     if (plane_eligible(T, W, C, radius, na) && !nodiv) {
         PlaneArgs pa{};
         pa.in = in; pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C; pa.axes = flags; pa.tp = tp;
@@ -473,10 +782,49 @@ extern "C" int kccot_smooth_bwd_f32(const float* gout, const float* out, const f
     const Taps tp = make_taps(sigma, radius);
     // ds goes where the adjoint chain wants its first source: (na passes) ... -> din
     float* ds = (na % 2 == 0) ? din : tmp;
-    hipLaunchKernelGGL(maxnorm_bwd_partial, dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, pdot, pcnt);
+    const bool wide = (n % 4 == 0) && ((uintptr_t)gout % 16 == 0) && ((uintptr_t)out % 16 == 0) && nb >= 2048;
+    const int64_t nparts = wide ? 2048 : nb;
+    if (wide) hipLaunchKernelGGL(maxnorm_bwd_partial_v4, dim3(2048), dim3(256), 0, st, gout, out, n / 4, pdot, pcnt);
+    else hipLaunchKernelGGL(maxnorm_bwd_partial, dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, pdot, pcnt);
     if ((rc = launch_status("maxnorm_bwd_partial"))) return rc;
-    hipLaunchKernelGGL(maxnorm_bwd_combine, dim3(1), dim3(1024), 0, st, (const float*)pdot, (const float*)pcnt, nb, res);
+    hipLaunchKernelGGL(maxnorm_bwd_combine, dim3(1), dim3(1024), 0, st, (const float*)pdot, (const float*)pcnt, nparts, res);
     if ((rc = launch_status("maxnorm_bwd_combine"))) return rc;
+    const unsigned axes = flags & (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W);
+    if ((radius == 3 || radius == 4) && !getenv("KCCOT_SMOOTH_NO_STREAM") &&
+        (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W))) {
+        const int64_t WC = (int64_t)W * C;
+        const bool three = axes != KCCOT_SMOOTH_T;
+        // adjoint stages in reverse order; the first one also applies the adjoint of the max-normalisation
+        const WalkPlan ph = three ? walk_plan(H, (int64_t)T * WC, true, gout, out, din) : WalkPlan{1, 32};
+        const WalkPlan pt = walk_plan(T, WC, !three, three ? (const void*)tmp : (const void*)gout, out, din);
+        const bool w1 = three && w1_eligible(W, C, radius, din, tmp);
+        if (pt.vw > 0 && ph.vw > 0 && (!three || w1 || plane_eligible(T, W, C, radius, 1))) {
+            WalkArgs wa{};
+            wa.tp = tp; wa.out_fwd = out; wa.mx = max_in; wa.res = res;
+            if (!three) {
+                wa.in = gout; wa.out = din; wa.L = T; wa.S = WC;
+                return launch_walk(WALK_ADJX, wa, radius, n, pt, st);
+            }
+            // H^T (+ normalisation adjoint): gout -> din;  W^T: din -> tmp;  T^T: tmp -> din
+            wa.in = gout; wa.out = din; wa.L = H; wa.S = (int64_t)T * WC;
+            if ((rc = launch_walk(WALK_ADJX, wa, radius, n, ph, st))) return rc;
+            if (w1) {
+                if ((rc = launch_w1(din, tmp, n, W, radius, true, tp, st))) return rc;
+            } else {
+                float* one = res + 4;                           // scalar slots behind {dot, ties}: {1, 0, 0}
+                if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x3f800000, 1, st) != hipSuccess ||
+                    hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one + 1), 0, 2, st) != hipSuccess)
+                    return fail(KCCOT_EINVAL, "smooth_bwd: memset failed");
+                PlaneArgs pa{};
+                pa.in = din; pa.out_fwd = out; pa.out = tmp; pa.mx = one; pa.res = one + 1;   // max = 1, no ties: plain W^T
+                pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C; pa.axes = KCCOT_SMOOTH_W; pa.tp = tp;
+                pa.hseg = plane_hseg(B, H, false);
+                if ((rc = launch_plane(pa, radius, true, dim3((H + pa.hseg - 1) / pa.hseg, B), st))) return rc;
+            }
+            wa.in = tmp; wa.out = din; wa.L = T; wa.S = WC;
+            return launch_walk(WALK_ADJ, wa, radius, n, pt, st);
+        }
+    }
     // The fused adjoint (smooth_plane<R,true>) is correct but measured slower than the per-axis
     // chain at the configs[1] shape (r01: 3-D fwd+bwd 524 us vs 402 us); opt-in until it is tuned.
     if (plane_eligible(T, W, C, radius, na) && getenv("KCCOT_SMOOTH_FUSED_BWD")) {

@@ -490,18 +490,48 @@ def test_smoothing_matches_oracle(shape):
     np.testing.assert_allclose(ks.gaussian_convolution3D(const, 5.0).cpu().numpy(), 1.0, rtol=1e-6)
 
 
-def test_smoothing_gradient_matches_autograd():
+@pytest.mark.parametrize("shape,ksize", [((2, 8, 9, 10, 2), 6),      # LDS plane kernel for W (W*C not a multiple of 4 pieces)
+                                         ((2, 8, 9, 16, 1), 6),      # register W kernel (C == 1), short axes
+                                         ((2, 40, 12, 8, 1), 6),     # H > 32: the 64-step walk; W = 8: two pieces per row
+                                         ((1, 12, 33, 12, 1), 8),    # radius 4, T > 32
+                                         ((2, 9, 10, 12, 3), 8)])    # radius 4, C = 3
+def test_smoothing_gradient_matches_autograd(shape, ksize):
     from kccotgan_amd.data_utils import KernelSmoothing
     from oracle import smoothing_torch as st
-    ks = KernelSmoothing(6, 6)
-    v = np.random.default_rng(4).random((2, 8, 9, 10, 2), dtype=np.float32)
+    ks = KernelSmoothing(ksize, ksize)
+    v = np.random.default_rng(4).random(shape, dtype=np.float32)
     wgt = np.random.default_rng(5).standard_normal(v.shape).astype(np.float32)
     for axes, fn in (((2,), ks.temporal_convolution), ((2, 1, 3), ks.gaussian_convolution3D)):
         a = torch.from_numpy(v).double().requires_grad_(True)
-        (st.smooth(a, 2.0, 3, axes) * torch.from_numpy(wgt).double()).sum().backward()
+        (st.smooth(a, 2.0, ksize // 2, axes) * torch.from_numpy(wgt).double()).sum().backward()
         b = torch.from_numpy(v).to(DEV).requires_grad_(True)
         (fn(b, 2.0) * torch.from_numpy(wgt).to(DEV)).sum().backward()
         np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.numpy(), rtol=0, atol=2e-4 * float(a.grad.abs().max()))
+
+
+def test_smoothing_stream_and_legacy_paths_agree():
+    """The streamed kernels (register walks along T / H, register W kernel) against the per-axis chain
+    they replace (KCCOT_SMOOTH_NO_STREAM=1): forward and gradient, at a shape that takes every fast path."""
+    from kccotgan_amd.data_utils import KernelSmoothing
+    ks = KernelSmoothing(6, 6)
+    v = torch.rand((3, 40, 30, 64, 1), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    wgt = torch.randn(v.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    res = {}
+    for mode in ("stream", "legacy"):
+        if mode == "legacy":
+            os.environ["KCCOT_SMOOTH_NO_STREAM"] = "1"
+        try:
+            for name, fn in (("t", ks.temporal_convolution), ("3d", ks.gaussian_convolution3D)):
+                x = v.clone().requires_grad_(True)
+                y = fn(x, 3.0)
+                (g,) = torch.autograd.grad(y, x, wgt)
+                res[mode, name] = (y.detach().cpu().numpy(), g.cpu().numpy())
+        finally:
+            os.environ.pop("KCCOT_SMOOTH_NO_STREAM", None)
+    for name in ("t", "3d"):
+        np.testing.assert_allclose(res["stream", name][0], res["legacy", name][0], rtol=2e-6, atol=1e-7)
+        gs, gl = res["stream", name][1], res["legacy", name][1]
+        np.testing.assert_allclose(gs, gl, rtol=0, atol=2e-6 * float(np.abs(gl).max()))
 
 
 # ---------------------------------------------------------------- extension: RBF kernel / MMD (no reference behaviour)
