@@ -35,6 +35,16 @@ constexpr int GPITCH = GRAM_KT + 4;   // 36 floats: conflict-free ds_read_b128 o
 constexpr int GRAM_SLABS = 12;        // 10 sub-tiles + 2 second halves of the k-split ones
 constexpr int GRAM_ELEMS = GRAM_NSUB * 1024;
 
+// The causal sums  caus[slot][i][j] = sum_{t<T-1,q} h[i,t,q] (M[j,t+1,q] - M[j,t,q])  (gan_utils.py:37-46) do
+// not depend on the Gram sums.  They are produced by spare workgroups of an earlier launch so that
+// gram_finalize only gathers and adds.
+struct CausalPre {
+    const float* h[3];   // per slot: rows; null = slot unused
+    const float* M[3];   // per slot: columns
+    float* caus;         // [3][B1][B2]
+    int B1, B2, T, J, nti, ntj;
+};
+
 struct GramArgs {
     const float* src1;
     const float* src2;
@@ -43,7 +53,21 @@ struct GramArgs {
     unsigned mask;       // needed sub-tiles, bit sub_index(a,b)
     int64_t K, chunk;
     float* gpart;        // [nchunk][GRAM_SLABS][1024]
+    int nchunk;          // workgroups [0, nchunk) do Gram chunks ...
+    int ntiles;          // ... and workgroups nchunk + b (b < gridDim.x - nchunk) the causal tiles b, b + nb, ... < ntiles
+    CausalPre cp;
 };
+
+// one 16x16 tile of causal sums by 256 threads (every one of them must call it); sh / sm: LDS scratch
+__device__ __forceinline__ void causal_pre_tile(const CausalPre& cp, int tile, float* sh, float* sm, int t) {
+    const int per = cp.nti * cp.ntj;
+    const int slot = tile / per, rem = tile % per;
+    if (slot >= 3 || cp.h[slot] == nullptr) return;      // uniform
+    const int i0 = (rem / cp.ntj) * CAUSAL_TILE, j0 = (rem % cp.ntj) * CAUSAL_TILE;
+    const float v = causal_tile16(cp.h[slot], cp.M[slot], i0, j0, cp.B1, cp.B2, cp.T, cp.J, sh, sm, t);
+    const int i = i0 + (t >> 4), j = j0 + (t & 15);
+    if (i < cp.B1 && j < cp.B2) cp.caus[((int64_t)slot * cp.B1 + i) * cp.B2 + j] = v;
+}
 
 struct WaveWork {        // up to three (sub-tile, k-group range) entries per wave
     int a[3], b[3], slab[3], lo[3], hi[3];
@@ -445,6 +469,16 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if ((int)blockIdx.x >= ga.nchunk) {
+        // spare workgroups (the K-split leaves a few CUs without a chunk): the causal sums, a few tiles
+        // each, finished long before the Gram chunks are
+        if (t >= 256) return;                                // whole waves; the barriers below count the live ones
+        float* sh = reinterpret_cast<float*>(zsA);
+        float* sm = sh + CAUSAL_TILE * CAUSAL_PITCH;
+        for (int tile = blockIdx.x - ga.nchunk; tile < ga.ntiles; tile += gridDim.x - ga.nchunk)
+            causal_pre_tile(ga.cp, tile, sh, sm, t);
+        return;
+    }
     const int64_t kbeg = (int64_t)blockIdx.x * ga.chunk;
     const int64_t kend = (kbeg + ga.chunk < ga.K) ? kbeg + ga.chunk : ga.K;
     if (kbeg >= kend) return;
@@ -535,12 +569,6 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
 // so one tile per CU; the other waves retire at once), results to `caus` [slot][B1][B2].
 // gram_finalize then only gathers and adds -- its dependent chain (launch -> Gram gathers -> feature
 // loads -> LDS dot products) was as long as the whole reduction.
-struct CausalPre {
-    const float* h[3];   // per slot: rows; null = slot unused
-    const float* M[3];   // per slot: columns
-    float* caus;         // [3][B1][B2]
-    int B1, B2, T, J, nti, ntj;
-};
 
 enum { GRAM_SPLIT_NONE = 0, GRAM_SPLIT_89 = 1, GRAM_SPLIT_26 = 2 };
 
@@ -551,14 +579,7 @@ __global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gp
     __shared__ __attribute__((aligned(16))) float csm[CAUSAL_TILE * CAUSAL_PITCH];
     if (blockIdx.x >= GRAM_ELEMS / 64) {
         if (threadIdx.x >= 256) return;                      // whole waves; barriers below count the live ones
-        const int tile = blockIdx.x - GRAM_ELEMS / 64;
-        const int per = cp.nti * cp.ntj;
-        const int slot = tile / per, rem = tile % per;
-        if (slot >= 3 || cp.h[slot] == nullptr) return;      // block-uniform
-        const int i0 = (rem / cp.ntj) * CAUSAL_TILE, j0 = (rem % cp.ntj) * CAUSAL_TILE;
-        const float v = causal_tile16(cp.h[slot], cp.M[slot], i0, j0, cp.B1, cp.B2, cp.T, cp.J, csh, csm);
-        const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
-        if (i < cp.B1 && j < cp.B2) cp.caus[((int64_t)slot * cp.B1 + i) * cp.B2 + j] = v;
+        causal_pre_tile(cp, blockIdx.x - GRAM_ELEMS / 64, csh, csm, threadIdx.x);
         return;
     }
     const int t = threadIdx.x, el = t & 63, grp = t >> 6;
@@ -754,21 +775,7 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     ga.K = K; ga.chunk = pl.chunk;
     ga.gpart = static_cast<float*>(ws);
     double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.gpart_bytes);
-    int split_mode = (ga.mask == 0x3FFu) ? GRAM_SPLIT_89 : GRAM_SPLIT_NONE;
-    if (ga.mask == 0x3FFu && gram_use_x3()) {
-        const char* e = getenv("KCCOT_GRAM_WS");   // =0: the single-role x3 kernel (A/B)
-        if (e && atoi(e) == 0) hipLaunchKernelGGL(gram128_partial_x3, dim3(pl.nchunk), dim3(256), 0, st, ga);
-        else {
-            const char* d = getenv("KCCOT_GRAM_DEEP");   // =1: two stages of loads in flight (A/B: measured 1-2 us SLOWER)
-            if (d && atoi(d) == 1) hipLaunchKernelGGL(gram128_partial_x3ws<true>, dim3(pl.nchunk), dim3(512), 0, st, ga);
-            else hipLaunchKernelGGL(gram128_partial_x3ws<false>, dim3(pl.nchunk), dim3(512), 0, st, ga);
-            split_mode = GRAM_SPLIT_26;
-        }
-    }
-    else if (ga.mask == 0x3FFu) hipLaunchKernelGGL(gram128_partial<true>, dim3(pl.nchunk), dim3(256), 0, st, ga);
-    else hipLaunchKernelGGL(gram128_partial<false>, dim3(pl.nchunk), dim3(256), 0, st, ga);
-    int rc = launch_status("gram128_partial");
-    if (rc || partial_only) return rc;
+    // causal sums: slots and tiles
     CausalPre cp{};
     cp.caus = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.gpart_bytes + pl.gsum_bytes);
     cp.B1 = gf.B1; cp.B2 = gf.B2; cp.T = T; cp.J = J;
@@ -780,7 +787,26 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
         cp.h[0] = gf.h[0]; cp.M[0] = gf.M[0]; cp.h[1] = gf.h2; cp.M[1] = gf.M2;
         nslot = gf.h2 ? 2 : (gf.h[0] ? 1 : 0);
     }
-    const int ncausal = nslot * cp.nti * cp.ntj;
+    int ncausal = nslot * cp.nti * cp.ntj;                  // tiles still to be done by gram_reduce's extra workgroups
+    ga.nchunk = pl.nchunk; ga.ntiles = 0; ga.cp = cp;
+    int split_mode = (ga.mask == 0x3FFu) ? GRAM_SPLIT_89 : GRAM_SPLIT_NONE;
+    if (ga.mask == 0x3FFu && gram_use_x3()) {
+        const char* e = getenv("KCCOT_GRAM_WS");   // =0: the single-role x3 kernel (A/B)
+        if (e && atoi(e) == 0) hipLaunchKernelGGL(gram128_partial_x3, dim3(pl.nchunk), dim3(256), 0, st, ga);
+        else {
+            // 16 spare workgroups (one per CU the 240-way K-split leaves idle) take the causal tiles
+            int spare = 0;
+            if (ncausal > 0 && !partial_only) { spare = ncausal < 16 ? ncausal : 16; ga.ntiles = ncausal; ncausal = 0; }
+            const char* d = getenv("KCCOT_GRAM_DEEP");   // =1: two stages of loads in flight (A/B: measured 1-2 us SLOWER)
+            if (d && atoi(d) == 1) hipLaunchKernelGGL(gram128_partial_x3ws<true>, dim3(pl.nchunk + spare), dim3(512), 0, st, ga);
+            else hipLaunchKernelGGL(gram128_partial_x3ws<false>, dim3(pl.nchunk + spare), dim3(512), 0, st, ga);
+            split_mode = GRAM_SPLIT_26;
+        }
+    }
+    else if (ga.mask == 0x3FFu) hipLaunchKernelGGL(gram128_partial<true>, dim3(pl.nchunk), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL(gram128_partial<false>, dim3(pl.nchunk), dim3(256), 0, st, ga);
+    int rc = launch_status("gram128_partial");
+    if (rc || partial_only) return rc;
     hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 64 + ncausal), dim3(1024), 0, st,
                        (const float*)ga.gpart, pl.nchunk, ga.mask, split_mode, gsum, cp);
     rc = launch_status("gram_reduce");
