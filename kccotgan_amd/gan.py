@@ -17,11 +17,22 @@ Videos cross the boundary in the reference's [B, H, T, W, C] layout.  Numerics a
 PARITY UNPINNED (no TensorFlow, no weights, no tests in the reference): padding follows TF 'same'
 arithmetic, recurrent activation is Keras' hard_sigmoid, initialisation is PyTorch's default.
 """
+import contextlib
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+# Layer families listed in KCCOT_NATIVE_CONV (comma separated: convlstm, deconv, dconv) run on the native
+# ATen convolution kernels instead of MIOpen's.  Default: see _NATIVE_DEFAULT / DESIGN.md section 7.
+_NATIVE_DEFAULT = ""
+_NATIVE = set(filter(None, os.environ.get("KCCOT_NATIVE_CONV", _NATIVE_DEFAULT).split(",")))
+
+
+def _backend(kind):
+    return torch.backends.cudnn.flags(enabled=False) if kind in _NATIVE else contextlib.nullcontext()
 
 
 def _same_pad(size, k, s):
@@ -66,13 +77,15 @@ class ConvLSTM2D(nn.Module):
 
     def forward(self, x):                             # [B, T, C, H, W] -> [B, T, F, H', W']
         B, T = x.shape[:2]
-        gx = self.wx(F.pad(x.reshape((B * T,) + x.shape[2:]), self.pad_x))   # all frames in one conv
+        with _backend("convlstm"):
+            gx = self.wx(F.pad(x.reshape((B * T,) + x.shape[2:]), self.pad_x))   # all frames in one conv
         gx = gx.reshape(B, T, 4 * self.filters, *self.out_hw)
         h = x.new_zeros(B, self.filters, *self.out_hw)
         c = torch.zeros_like(h)
         outs = []
         for t in range(T):
-            g = gx[:, t] + self.wh(F.pad(h, self.pad_h))
+            with _backend("convlstm"):
+                g = gx[:, t] + self.wh(F.pad(h, self.pad_h))
             gi, gf, gc, go = torch.chunk(g, 4, dim=1)
             c = hard_sigmoid(gf) * c + hard_sigmoid(gi) * torch.tanh(gc)
             h = hard_sigmoid(go) * torch.tanh(c)
@@ -94,9 +107,10 @@ class _SameConvTranspose(nn.Module):
             self.conv = nn.ConvTranspose2d(in_ch, filters, k, s, padding=(k - s) // 2, bias=False)
 
     def forward(self, x):
-        if self.s == 1:
-            return self.conv(F.pad(x, (self.pad[0], self.pad[1], self.pad[0], self.pad[1])))
-        return self.conv(x)
+        with _backend("deconv"):
+            if self.s == 1:
+                return self.conv(F.pad(x, (self.pad[0], self.pad[1], self.pad[0], self.pad[1])))
+            return self.conv(x)
 
 
 def _to_frames(video):
@@ -263,7 +277,8 @@ class VideoDiscriminator(nn.Module):
         B, T = x.shape[:2]
         z = x.reshape((B * T,) + x.shape[2:])
         for conv, bn, pad in zip(self.convs, self.conv_bn, self.pads):
-            z = conv(F.pad(z, pad))
+            with _backend("dconv"):
+                z = conv(F.pad(z, pad))
             if self.bn:
                 z = bn(z)
             z = F.leaky_relu(z, 0.3)                   # Keras LeakyReLU default alpha

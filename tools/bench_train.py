@@ -5,10 +5,12 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+if os.environ.get("KCCOT_TRAIN_MIOPEN") != "1":
+    torch.backends.cudnn.enabled = False      # see DESIGN.md section 7: MIOpen kernels of the generator backward fault
 from kccotgan_amd.kernel_train import KCCOTTrainer
 
 
-def run(kernel, iters=3, B=64):
+def run(kernel, iters=5, B=64):
     tr = KCCOTTrainer(B, total_time_steps=30, int_time_steps=5, x_height=64, x_width=64, channels=1, kernel=kernel,
                       device="cuda:0")
     x = torch.rand(B, 64, 30, 64, 1, device="cuda:0")
