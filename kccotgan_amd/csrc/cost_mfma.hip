@@ -437,6 +437,9 @@ __device__ __forceinline__ void x3ws_consume(const unsigned char* zsA, const uns
         const unsigned char* zs = (s & 1) ? zsB : zsA;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
+#if defined(KCCOT_GRAM_EXP) && KCCOT_GRAM_EXP == 1
+            continue;   // diagnostic build: consumers only keep the barriers (producer-limited time)
+#endif
             const Frag3 fx = ld_frag3(zs, ox + kb * 32), fy = ld_frag3(zs, oy + kb * 32);
             mfma_x3(acc0, fx, fx);
             if (W != 3) mfma_x3(acc1, fx, fy); else mfma_x3(acc1, fy, fx);      // (X,Y), or (0,3) = (Y,X) for W = 3
@@ -510,11 +513,20 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
         }
         for (int s = 0; s <= nstage; ++s) {
             // stage s goes into buffer s&1 (the consumers read it during iteration s+1 of this loop)
+#if defined(KCCOT_GRAM_EXP) && KCCOT_GRAM_EXP == 2
+            if (false) {   // diagnostic build: producers only keep the barriers (consumer-limited time)
+#else
             if (s < nstage) {
+#endif
                 unsigned char* zb = (s & 1) ? zsB : zsA;
                 if (!deep || (s & 1) == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+#if defined(KCCOT_GRAM_EXP) && KCCOT_GRAM_EXP == 3
+                        // diagnostic build: global loads only, one cheap use so that they are not dropped
+                        if (v[j].x + v[j + 4].x == 1234.5f) zb[wbase] = 1;
+                        continue;
+#endif
                         if (ga.pair_diff) {
                             v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
                         }
