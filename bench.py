@@ -162,10 +162,15 @@ def main():
         # the step as a training loop would run it: forward + backward captured once into a hipGraph
         # (kccotgan_amd/graph.py) and replayed -- the same eight kernels with the same arguments, one
         # hipGraphLaunch instead of eight launches issued from Python
-        from kccotgan_amd.graph import GraphedLossStep
-        graphed = GraphedLossStep(t, SC)
-        step = lambda: graphed()
-        mode = "hipGraph replay of forward+backward"
+        try:
+            from kccotgan_amd.graph import GraphedLossStep
+            graphed = GraphedLossStep(t, SC)
+            step = lambda: graphed()
+            mode = "hipGraph replay of forward+backward"
+        except Exception as e:   # capture is an optimisation of the launch path, never a reason to lose the measurement
+            sys.stderr.write("bench: graph capture failed (%r); timing eager launches\n" % (e,))
+            torch.cuda.synchronize()
+            step = lambda: loss_step(G, t)
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,6 +211,7 @@ def main():
                    "launch": mode, "loss": float(loss)},
     }
     if rank == 0 and world == 1:
+      try:
         # the shipped default: exact shortcut on.  Same outputs bit for bit (tests/test_gpu_parity.py::
         # test_sinkhorn_periodic_state_shortcut_is_bit_exact); how much it saves depends on the data.
         os.environ["KCCOT_SK_NO_SHORTCUT"] = "0"
@@ -234,7 +240,11 @@ def main():
         out["with_exact_shortcut"] = extra
         os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
         out["eager_launches_ms_per_step"] = timed(lambda: loss_step(G, t))[0]     # shortcut off, like the headline
+      except Exception as e:     # auxiliary measurements must not cost the headline line
+        sys.stderr.write("bench: auxiliary timings failed: %r\n" % (e,))
+        os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
     if rank == 0 and world == 1:
+      try:
         kt, K = time_cost_kernel(t)
         B, T, J = SHAPE["B"], SHAPE["T"], SHAPE["J"]
         alg_bytes = 2 * B * K * 4 + 16 * B * T * J + 12 * B * B            # read real+fake once
@@ -268,9 +278,14 @@ def main():
                      "hbm_achieved_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
                      "algorithmic_flops": alg_flops})
         out["roofline"] = roof
+      except Exception as e:
+        sys.stderr.write("bench: roofline block failed: %r\n" % (e,))
+      try:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(inp)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+      except Exception as e:
+        sys.stderr.write("bench: cpu_baseline failed: %r\n" % (e,))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
