@@ -225,7 +225,7 @@ template <int NSTEPS>
 __global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict__ Wt, int wpitch,
                                                          const float* __restrict__ src1, int n1,
                                                          const float* __restrict__ src2, int n2, int Bout,
-                                                         int64_t K, int64_t ntiles, float* __restrict__ out) {
+                                                         int64_t K, int64_t ntiles, float* __restrict__ out, int accumulate) {
     __shared__ __attribute__((aligned(16))) float zs[AM_ROWS * AM_COLS];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -280,7 +280,11 @@ __global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = 32 * mblk + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < Bout) out[(int64_t)m * K + col] = acc[r];
+                if (m < Bout) {
+                    // blocked use (more than 128 stack rows): later stack chunks add to the earlier ones' result
+                    float* o = out + (int64_t)m * K + col;
+                    *o = accumulate ? *o + acc[r] : acc[r];
+                }
             }
         }
     }
@@ -291,15 +295,36 @@ __global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict
 static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, const float* s2, int n2, int Bout,
                         int64_t K, float* out, hipStream_t st) {
     const bool al = (K % 4 == 0) && ((uintptr_t)s1 % 16 == 0) && (n2 == 0 || (uintptr_t)s2 % 16 == 0);
-    if (al && n1 + n2 <= AM_ROWS && Bout <= 64) {
+    if (al) {
+        // MFMA kernel on blocks: 64 output rows x (up to) 128 stack rows at a time.  One block covers the
+        // BASELINE configs[1] batch in a single launch; larger batches run (Bout/64) x (R/128) launches, the
+        // later stack chunks accumulating into the output (stream order keeps the sum deterministic).
         const int64_t ntiles = (K + AM_COLS - 1) / AM_COLS;
         const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);   // 2 workgroups per CU (VGPR-limited)
         const int R = n1 + n2;
-        const float* s2p = s2 ? s2 : s1;
-        if (R > 64) hipLaunchKernelGGL(apply_coeffs_mfma<64>, dim3(grid), dim3(256), 0, st, Wt, wpitch, s1, n1, s2p, n2, Bout, K, ntiles, out);
-        else if (R > 32) hipLaunchKernelGGL(apply_coeffs_mfma<32>, dim3(grid), dim3(256), 0, st, Wt, wpitch, s1, n1, s2p, n2, Bout, K, ntiles, out);
-        else hipLaunchKernelGGL(apply_coeffs_mfma<16>, dim3(grid), dim3(256), 0, st, Wt, wpitch, s1, n1, s2p, n2, Bout, K, ntiles, out);
-        return launch_status("apply_coeffs_mfma");
+        for (int ob = 0; ob < Bout; ob += 64) {
+            const int bo = Bout - ob < 64 ? Bout - ob : 64;
+            for (int r0 = 0; r0 < R; r0 += AM_ROWS) {
+                const int r1 = r0 + AM_ROWS < R ? r0 + AM_ROWS : R;
+                // rows [r0, r1) of the stack: the part inside src1, then the part inside src2
+                const int a0 = r0 < n1 ? r0 : n1, a1 = r1 < n1 ? r1 : n1;
+                const int b0 = r0 > n1 ? r0 - n1 : 0, b1 = r1 > n1 ? r1 - n1 : 0;
+                const int c1 = a1 - a0, c2 = b1 - b0;
+                const float* p1 = c1 > 0 ? s1 + (int64_t)a0 * K : s2 + (int64_t)b0 * K;
+                const float* p2 = c1 > 0 ? (c2 > 0 ? s2 + (int64_t)b0 * K : p1) : p1;
+                const int m1 = c1 > 0 ? c1 : c2, m2 = c1 > 0 ? c2 : 0;
+                const float* W = Wt + (int64_t)r0 * wpitch + ob;
+                float* o = out + (int64_t)ob * K;
+                const int acc = r0 > 0;
+                const int rr = r1 - r0;
+                if (rr > 64) hipLaunchKernelGGL(apply_coeffs_mfma<64>, dim3(grid), dim3(256), 0, st, W, wpitch, p1, m1, p2, m2, bo, K, ntiles, o, acc);
+                else if (rr > 32) hipLaunchKernelGGL(apply_coeffs_mfma<32>, dim3(grid), dim3(256), 0, st, W, wpitch, p1, m1, p2, m2, bo, K, ntiles, o, acc);
+                else hipLaunchKernelGGL(apply_coeffs_mfma<16>, dim3(grid), dim3(256), 0, st, W, wpitch, p1, m1, p2, m2, bo, K, ntiles, o, acc);
+                const int rc = launch_status("apply_coeffs_mfma");
+                if (rc) return rc;
+            }
+        }
+        return 0;
     }
     const unsigned gx = (unsigned)((K + 255) / 256);
     if (Bout <= 8) hipLaunchKernelGGL(apply_coeffs<8>, dim3(gx, 1), dim3(256), 0, st, Wt, wpitch, s1, n1, s2, n2, Bout, K, out);

@@ -8,6 +8,8 @@
 // the multi-CU cooperative solver that would split a problem over an XCD is not built yet.
 #include "common.h"
 #include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
 
 namespace kccot {
 
@@ -116,6 +118,130 @@ __global__ __launch_bounds__(SG_THREADS) void sinkhorn_fwd_gen(SinkGenArgs a) {
                 if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + j] = vn;
             }
         }
+        __syncthreads();
+        nits = it + 1;
+        const bool reached = (a.stop_mode == KCCOT_STOP_INDEX) ? (it >= a.Lmin) : (nits >= a.Lmin);
+        if (reached && it + 1 < a.L) {
+            const float err = block_sum(du, red);
+            if (a.thresh > err) break;
+        }
+    }
+    float part = 0.f;
+    for (int i = wid; i < n; i += nw) {
+        const float ui = u_s[i];
+        const float* row = C + (int64_t)i * n;
+        for (int j = lane; j < n; j += 64) {
+            const float c = row[j];
+            const float pi = __builtin_amdgcn_exp2f(((-c + ui) + v_s[j]) * inv_eps * SG_LOG2E);
+            part += pi * c;
+            if (a.pi_out) a.pi_out[(int64_t)p * n * n + (int64_t)i * n + j] = pi;
+        }
+    }
+    const float cost = block_sum(part, red);
+    if (t == 0) { a.cost_out[p] = cost; a.nits_out[p] = nits; a.nits_out[gridDim.x + p] = nits; }
+}
+
+// ---- forward, wide form (n % 4 == 0) --------------------------------------------------------------
+// Same arithmetic as sinkhorn_fwd_gen, restructured so that the stream from L2 is not a latency chain:
+// a wave takes RB lines at a time, every lane loads its 16-byte pieces of all of them (NV pieces per
+// line, n <= 256 NV) before the first use, the next group's loads are issued before the current group
+// is reduced, and each element is read once per half-step (the two-pass log-sum-exp runs on registers).
+// The other side's duals are read from LDS once per half-step per wave.
+template <int NV>
+__device__ __forceinline__ void gen_load_lines(float4 (&c)[8 / NV][NV], const float* __restrict__ M, int n, int first, int stride) {
+    constexpr int RB = 8 / NV;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int line = first + r * stride;
+        const int lc = line < n ? line : n - 1;                 // clamped: no predicated loads
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = 4 * lane + 256 * v;
+            const int ic = idx < n ? idx : n - 4;
+            c[r][v] = *reinterpret_cast<const float4*>(M + (int64_t)lc * n + ic);
+        }
+    }
+}
+
+template <int NV, bool ROW>
+__device__ __forceinline__ float gen_update_line(const float4 (&c)[NV], const float4 (&o)[NV], int n, float self, float eps,
+                                                 float inv_eps, float log_w) {
+    const int lane = threadIdx.x & 63;
+    float tt[NV][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float cc[4] = {c[v].x, c[v].y, c[v].z, c[v].w}, oo[4] = {o[v].x, o[v].y, o[v].z, o[v].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = 4 * lane + 256 * v + e < n;
+            const float t = ROW ? ((-cc[e] + self) + oo[e]) : ((-cc[e] + oo[e]) + self);
+            tt[v][e] = ok ? t * inv_eps : -INFINITY;
+            mx = fmaxf(mx, tt[v][e]);
+        }
+    }
+    mx = wave_max_fast(mx);
+    const float shift = (mx > -INFINITY && mx < INFINITY) ? mx : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += __builtin_amdgcn_exp2f((tt[v][e] - shift) * SG_LOG2E);
+    s = wave_sum_fast(s);
+    const float lse = __builtin_amdgcn_logf(s) * SG_LN2 + shift;
+    return eps * (log_w - lse) + self;
+}
+
+template <int NV>
+__global__ __launch_bounds__(SG_THREADS) void sinkhorn_fwd_gen4(SinkGenArgs a) {
+    constexpr int RB = 8 / NV;
+    __shared__ __attribute__((aligned(16))) float u_s[SG_MAXN], v_s[SG_MAXN];
+    __shared__ float red[16];
+    const int p = blockIdx.x, n = a.n;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, nw = SG_THREADS / 64;
+    const float* C = a.C + (int64_t)p * n * n;
+    const float* CT = a.CT + (int64_t)p * n * n;
+    const float eps = a.eps, inv_eps = a.inv_eps;
+    for (int i = t; i < SG_MAXN; i += SG_THREADS) { u_s[i] = 0.f; v_s[i] = 0.f; }
+    __syncthreads();
+    const float log_w = logf(1.0f / (float)n);
+    // one half-step: lines of M (rows of C, or rows of C^T), `self_s` updated in place, `other_s` read-only
+    auto half = [&](const float* M, float* self_s, const float* other_s, float* hist, bool row, float& du) {
+        float4 o[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = 4 * lane + 256 * v;
+            o[v] = idx < n ? *reinterpret_cast<const float4*>(other_s + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 cur[RB][NV], nxt[RB][NV];
+        gen_load_lines<NV>(cur, M, n, wid, nw);
+        for (int base = wid; base < n; base += nw * RB) {
+            if (base + nw * RB < n) gen_load_lines<NV>(nxt, M, n, base + nw * RB, nw);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int line = base + r * nw;
+                const float sv = self_s[line < n ? line : 0];
+                const float nv = row ? gen_update_line<NV, true>(cur[r], o, n, sv, eps, inv_eps, log_w)
+                                     : gen_update_line<NV, false>(cur[r], o, n, sv, eps, inv_eps, log_w);
+                if (line < n && lane == 0) {
+                    du += fabsf(nv - sv);
+                    self_s[line] = nv;          // read by this wave only during the pass
+                    if (hist) hist[line] = nv;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) cur[r][v] = nxt[r][v];
+        }
+    };
+    int nits = 0;
+    for (int it = 0; it < a.L; ++it) {
+        float du = 0.f, dv = 0.f;
+        half(C, u_s, v_s, a.u_hist ? a.u_hist + ((int64_t)p * a.L + it) * n : nullptr, true, du);
+        __syncthreads();
+        half(CT, v_s, u_s, a.v_hist ? a.v_hist + ((int64_t)p * a.L + it) * n : nullptr, false, dv);
         __syncthreads();
         nits = it + 1;
         const bool reached = (a.stop_mode == KCCOT_STOP_INDEX) ? (it >= a.Lmin) : (nits >= a.Lmin);
@@ -254,7 +380,11 @@ int launch_sinkhorn_fwd_gen(const float* C, int nprob, int n, float eps, int L, 
     int rc = launch_status("transpose_batched");
     if (rc) return rc;
     SinkGenArgs a{C, CT, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out};
-    hipLaunchKernelGGL(sinkhorn_fwd_gen, dim3(nprob), dim3(SG_THREADS), 0, st, a);
+    const bool wide = (n % 4 == 0) && ((uintptr_t)C % 16 == 0) && !getenv("KCCOT_SK_GEN_NARROW");
+    if (!wide) hipLaunchKernelGGL(sinkhorn_fwd_gen, dim3(nprob), dim3(SG_THREADS), 0, st, a);
+    else if (n <= 256) hipLaunchKernelGGL(sinkhorn_fwd_gen4<1>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
+    else if (n <= 512) hipLaunchKernelGGL(sinkhorn_fwd_gen4<2>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(sinkhorn_fwd_gen4<4>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
     return launch_status("sinkhorn_fwd_gen");
 }
 
