@@ -51,6 +51,33 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// ---- DPP reductions inside aligned groups of LPR <= 16 lanes; every lane gets the result -----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// max(v, dpp(v)) in ONE instruction.  fmaxf() on a DPP move costs mov + canonicalise + max; the
+// values here are never NaN-signalling, so the bare v_max_f32_dpp is exact.  The s_nop covers the
+// VALU-write -> DPP-read hazard (2 wait states) that hipcc does not pad inside an asm statement.
+#define KCCOT_DPP_MAX(V, CTRL)                                                                          \
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(V) : "v"(V))
+template <int LPR>
+__device__ __forceinline__ float seg_max(float v) {
+    if (LPR >= 2) KCCOT_DPP_MAX(v, "quad_perm:[1,0,3,2]");
+    if (LPR >= 4) KCCOT_DPP_MAX(v, "quad_perm:[2,3,0,1]");
+    if (LPR >= 8) KCCOT_DPP_MAX(v, "row_half_mirror");
+    if (LPR >= 16) KCCOT_DPP_MAX(v, "row_mirror");
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ float seg_sum(float v) {
+    if (LPR >= 2) v += dpp_mov<0xB1>(v);
+    if (LPR >= 4) v += dpp_mov<0x4E>(v);
+    if (LPR >= 8) v += dpp_mov<0x141>(v);
+    if (LPR >= 16) v += dpp_mov<0x140>(v);
+    return v;
+}
+
 // DPP forms for latency-critical loops: four in-row steps (every lane of a 16-lane row ends with its row's
 // result), then the four row results are read through SGPRs.  ~11 instructions and no LDS-crossbar round
 // trips (a __shfl_xor butterfly is six dependent ds_bpermute_b32).  The result is wave-uniform.

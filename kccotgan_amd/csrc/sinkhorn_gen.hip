@@ -265,6 +265,116 @@ __global__ __launch_bounds__(SG_THREADS) void sinkhorn_fwd_gen4(SinkGenArgs a) {
     if (t == 0) { a.cost_out[p] = cost; a.nits_out[p] = nits; a.nits_out[gridDim.x + p] = nits; }
 }
 
+// ---- forward, 16 lanes per line (n % 4 == 0, n <= 512) -----------------------------------------------
+// At n = 256 a line is 4 elements per lane of a 64-lane wave: the 64-wide reductions and the per-line
+// bookkeeping, not the elements, dominate the instruction stream, and the loop is issue-bound on its one
+// CU.  Here a wave instruction serves FOUR lines (16 lanes each, NV 16-byte pieces per lane per line,
+// n <= 64 NV), the reductions are the in-row DPP trees of the register kernels, and the lines of the
+// next group are loaded before the current group is reduced.
+template <int NV, bool ROW>
+__device__ __forceinline__ float gen16_update(const float4 (&c)[NV], const float4 (&o)[NV], int n, int q, float self,
+                                              float eps, float inv_eps, float log_w) {
+    float tt[NV][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float cc[4] = {c[v].x, c[v].y, c[v].z, c[v].w}, oo[4] = {o[v].x, o[v].y, o[v].z, o[v].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = 4 * q + 64 * v + e < n;
+            const float t = ROW ? ((-cc[e] + self) + oo[e]) : ((-cc[e] + oo[e]) + self);
+            tt[v][e] = ok ? t * inv_eps : -INFINITY;
+            mx = fmaxf(mx, tt[v][e]);
+        }
+    }
+    mx = seg_max<16>(mx);
+    const float shift = (mx > -INFINITY && mx < INFINITY) ? mx : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += __builtin_amdgcn_exp2f((tt[v][e] - shift) * SG_LOG2E);
+    s = seg_sum<16>(s);
+    const float lse = __builtin_amdgcn_logf(s) * SG_LN2 + shift;
+    return eps * (log_w - lse) + self;
+}
+
+template <int NV>
+__global__ __launch_bounds__(SG_THREADS) void sinkhorn_fwd_gen16(SinkGenArgs a) {
+    __shared__ __attribute__((aligned(16))) float u_s[SG_MAXN], v_s[SG_MAXN];
+    __shared__ float red[16];
+    const int p = blockIdx.x, n = a.n;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, nw = SG_THREADS / 64;
+    const int q = lane & 15, sub = lane >> 4;
+    const float* C = a.C + (int64_t)p * n * n;
+    const float* CT = a.CT + (int64_t)p * n * n;
+    const float eps = a.eps, inv_eps = a.inv_eps;
+    for (int i = t; i < SG_MAXN; i += SG_THREADS) { u_s[i] = 0.f; v_s[i] = 0.f; }
+    __syncthreads();
+    const float log_w = logf(1.0f / (float)n);
+    const int ngroups = (n + 3) >> 2;
+    auto load_group = [&](float4 (&c)[NV], const float* M, int g) {
+        const int line = 4 * g + sub;
+        const int lc = line < n ? line : n - 1;                 // clamped: no predicated loads
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = 4 * q + 64 * v;
+            c[v] = *reinterpret_cast<const float4*>(M + (int64_t)lc * n + (idx < n ? idx : n - 4));
+        }
+    };
+    auto half = [&](const float* M, float* self_s, const float* other_s, float* hist, bool row, float& du) {
+        float4 o[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = 4 * q + 64 * v;
+            o[v] = idx < n ? *reinterpret_cast<const float4*>(other_s + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 cur[NV], nxt[NV];
+        if (wid < ngroups) load_group(cur, M, wid);
+        for (int g = wid; g < ngroups; g += nw) {
+            if (g + nw < ngroups) load_group(nxt, M, g + nw);
+            const int line = 4 * g + sub;
+            const float sv = self_s[line < n ? line : 0];
+            const float nv = row ? gen16_update<NV, true>(cur, o, n, q, sv, eps, inv_eps, log_w)
+                                 : gen16_update<NV, false>(cur, o, n, q, sv, eps, inv_eps, log_w);
+            if (line < n && q == 0) {
+                du += fabsf(nv - sv);
+                self_s[line] = nv;              // read by this wave only during the pass
+                if (hist) hist[line] = nv;
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) cur[v] = nxt[v];
+        }
+    };
+    int nits = 0;
+    for (int it = 0; it < a.L; ++it) {
+        float du = 0.f, dv = 0.f;
+        half(C, u_s, v_s, a.u_hist ? a.u_hist + ((int64_t)p * a.L + it) * n : nullptr, true, du);
+        __syncthreads();
+        half(CT, v_s, u_s, a.v_hist ? a.v_hist + ((int64_t)p * a.L + it) * n : nullptr, false, dv);
+        __syncthreads();
+        nits = it + 1;
+        const bool reached = (a.stop_mode == KCCOT_STOP_INDEX) ? (it >= a.Lmin) : (nits >= a.Lmin);
+        if (reached && it + 1 < a.L) {
+            const float err = block_sum(du, red);
+            if (a.thresh > err) break;
+        }
+    }
+    float part = 0.f;
+    for (int i = wid; i < n; i += nw) {
+        const float ui = u_s[i];
+        const float* row = C + (int64_t)i * n;
+        for (int j = lane; j < n; j += 64) {
+            const float c = row[j];
+            const float pi = __builtin_amdgcn_exp2f(((-c + ui) + v_s[j]) * inv_eps * SG_LOG2E);
+            part += pi * c;
+            if (a.pi_out) a.pi_out[(int64_t)p * n * n + (int64_t)i * n + j] = pi;
+        }
+    }
+    const float cost = block_sum(part, red);
+    if (t == 0) { a.cost_out[p] = cost; a.nits_out[p] = nits; a.nits_out[gridDim.x + p] = nits; }
+}
+
 struct SinkGenBwdArgs {
     const float* C;
     const float* CT;
@@ -381,7 +491,10 @@ int launch_sinkhorn_fwd_gen(const float* C, int nprob, int n, float eps, int L, 
     if (rc) return rc;
     SinkGenArgs a{C, CT, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out};
     const bool wide = (n % 4 == 0) && ((uintptr_t)C % 16 == 0) && !getenv("KCCOT_SK_GEN_NARROW");
+    const bool sixteen = !getenv("KCCOT_SK_GEN_WAVE_LINES");   // =1: one line per wave instruction (A/B)
     if (!wide) hipLaunchKernelGGL(sinkhorn_fwd_gen, dim3(nprob), dim3(SG_THREADS), 0, st, a);
+    else if (n <= 256 && sixteen) hipLaunchKernelGGL(sinkhorn_fwd_gen16<4>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
+    else if (n <= 512 && sixteen) hipLaunchKernelGGL(sinkhorn_fwd_gen16<8>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
     else if (n <= 256) hipLaunchKernelGGL(sinkhorn_fwd_gen4<1>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
     else if (n <= 512) hipLaunchKernelGGL(sinkhorn_fwd_gen4<2>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
     else hipLaunchKernelGGL(sinkhorn_fwd_gen4<4>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
