@@ -26,8 +26,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 # Layer families listed in KCCOT_NATIVE_CONV (comma separated: convlstm, deconv, dconv) run on the native
-# ATen convolution kernels instead of MIOpen's.  Default: see _NATIVE_DEFAULT / DESIGN.md section 7.
-_NATIVE_DEFAULT = ""
+# ATen convolution kernels instead of MIOpen's.  Default: all three -- with MIOpen's convolutions the
+# backward of the generator overruns a buffer on this ROCm image (a pure-PyTorch loop faults as soon as the
+# allocator layout exposes it).  KCCOT_NATIVE_CONV= (empty) selects MIOpen: 9x faster
+# per training iteration when it does not fault.
+_NATIVE_DEFAULT = "convlstm,deconv,dconv"
 _NATIVE = set(filter(None, os.environ.get("KCCOT_NATIVE_CONV", _NATIVE_DEFAULT).split(",")))
 
 
