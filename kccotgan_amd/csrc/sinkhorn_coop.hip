@@ -1,0 +1,380 @@
+// Multi-CU Sinkhorn for 128 < n <= 1024 (BASELINE configs 3-5 batch sizes).
+//
+// One CU streaming an n x n cost matrix per half-step is issue-bound (n = 256: 5-10 us per half-step, n = 512:
+// four times that).  Here a problem is spread over ceil(n/16) workgroups: workgroup g owns lines 16g .. 16g+15,
+// one wave per line, and keeps BOTH orientations of its lines (row i of C and column i of C, n/64 entries per
+// lane each) in registers for the whole solve -- the matrix is read once.  A half-step is then a few dozen
+// instructions per wave; what it costs is the exchange: every workgroup publishes its 16 new duals, all
+// workgroups of the problem meet at a device-wide barrier, and every lane re-reads the n/64 duals of its
+// columns.  Two barriers per iteration (~2 us each) replace two passes over the matrix.
+//
+// The barrier is a monotonically increasing arrival counter in global memory (one per problem, zeroed by a
+// memset node in front of the launch): thread 0 of a workgroup publishes with an agent-scope release fence and
+// an atomic add, then polls -- with a bounded number of polls: if the workgroups of a problem are not all
+// resident (they are: at most 192 workgroups of 1024 threads on 256 CUs, nothing else on the stream) or
+// anything else goes wrong, the poll gives up, raises an abort flag that every later barrier honours at once,
+// and the kernel drains instead of hanging the device.  Exchange data is read with agent-scope (L1-bypassing)
+// loads after an acquire fence: the workgroups of one problem may sit on different XCDs, each with its own L2.
+#include "common.h"
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+namespace kccot {
+
+constexpr int SC_LINES = 16;                 // lines (= waves) per workgroup
+constexpr int SC_THREADS = SC_LINES * 64;
+constexpr int SC_MAXWG = 64;                 // n <= 1024
+constexpr unsigned SC_SPIN_LIMIT = 1u << 20; // polls (an L2 round trip each) before a barrier gives up: ~1 s
+constexpr float SC_LOG2E = 1.4426950408889634f;
+constexpr float SC_LN2 = 0.6931471805599453f;
+
+struct CoopCtrl {            // per launch, zeroed in front of it
+    unsigned bar[32];        // arrival counters, one per problem
+    int abort_flag;
+    int pad[31];
+};
+
+// Returns false if the solve has been aborted.  `phase` counts this problem's barriers (1, 2, ...).
+__device__ __forceinline__ bool grid_barrier(CoopCtrl* ctrl, int p, unsigned nwg, unsigned phase, int* lds_flag) {
+    __syncthreads();                                   // every wave's stores of this phase are issued
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(&ctrl->bar[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = phase * nwg;
+        unsigned spins = 0;
+        int ab = 0;
+        while (__hip_atomic_load(&ctrl->bar[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            ab = __hip_atomic_load(&ctrl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ab) break;
+            if (++spins > SC_SPIN_LIMIT) {
+                __hip_atomic_store(&ctrl->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ab = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *lds_flag = ab;
+    }
+    __syncthreads();
+    return *lds_flag == 0;
+}
+
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct SinkCoopArgs {
+    const float* C;
+    int n, L, Lmin, stop_mode;
+    float eps, inv_eps, thresh;
+    float* u_hist;
+    float* v_hist;
+    float* cost_out;
+    int32_t* nits_out;
+    float* pi_out;
+    CoopCtrl* ctrl;
+    float* xu;       // [nprob][n] exchange: current u
+    float* xv;       // [nprob][n]
+    float* errp;     // [nprob][2][SC_MAXWG] per-workgroup sum |du| of the u-update, double-buffered by iteration parity
+    float* costp;    // [nprob][SC_MAXWG]
+};
+
+// one line's dual update: lane holds entries idx = lane + 64 e of its line (c) and of the other side's duals (o)
+template <int EPT, bool ROW>
+__device__ __forceinline__ float coop_update(const float (&c)[EPT], const float (&o)[EPT], int n, int lane, float self, float eps,
+                                             float inv_eps, float log_w) {
+    float tt[EPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const float t = ROW ? ((-c[e] + self) + o[e]) : ((-c[e] + o[e]) + self);   // gan_utils.py:153-156
+        tt[e] = (lane + 64 * e < n) ? t * inv_eps : -INFINITY;
+        mx = fmaxf(mx, tt[e]);
+    }
+    mx = wave_max_fast(mx);
+    const float shift = (mx > -INFINITY && mx < INFINITY) ? mx : 0.f;       // tf.reduce_logsumexp
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) s += __builtin_amdgcn_exp2f((tt[e] - shift) * SC_LOG2E);
+    s = wave_sum_fast(s);
+    const float lse = __builtin_amdgcn_logf(s) * SC_LN2 + shift;
+    return eps * (log_w - lse) + self;
+}
+
+template <int EPT>
+__global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_coop(SinkCoopArgs a) {
+    __shared__ float red[SC_LINES];
+    __shared__ int bflag;
+    const int p = blockIdx.y, wg = blockIdx.x, n = a.n;
+    const unsigned nwg = gridDim.x;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int line = wg * SC_LINES + w;
+    const bool live = line < n;
+    const int lsafe = live ? line : n - 1;
+    const float* C = a.C + (int64_t)p * n * n;
+    float* xu = a.xu + (int64_t)p * n;
+    float* xv = a.xv + (int64_t)p * n;
+    float* errp = a.errp + p * 2 * SC_MAXWG;   // slot it & 1: the next iteration's writers must not race this one's readers
+    const float eps = a.eps, inv_eps = a.inv_eps;
+    const float log_w = logf(1.0f / (float)n);
+
+    float crow[EPT], ccol[EPT], ov[EPT], ou[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = lane + 64 * e;
+        const int ic = idx < n ? idx : n - 1;                     // clamped address, masked in coop_update
+        crow[e] = C[(int64_t)lsafe * n + ic];
+        ccol[e] = C[(int64_t)ic * n + lsafe];
+        ov[e] = 0.f; ou[e] = 0.f;                                  // gan_utils.py:147: u = v = 0
+    }
+    float ui = 0.f, vj = 0.f;
+    unsigned phase = 0;
+    int nits = 0;
+    bool ok = true;
+    for (int it = 0; it < a.L && ok; ++it) {
+        const float un = coop_update<EPT, true>(crow, ov, n, lane, ui, eps, inv_eps, log_w);
+        const float du = live ? fabsf(un - ui) : 0.f;
+        ui = un;
+        if (lane == 0) {
+            red[w] = du;
+            if (live) {
+                xu[line] = un;
+                if (a.u_hist) a.u_hist[((int64_t)p * a.L + it) * n + line] = un;
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < SC_LINES; ++k) s += red[k];
+            errp[(it & 1) * SC_MAXWG + wg] = s;
+        }
+        if (!(ok = grid_barrier(a.ctrl, p, nwg, ++phase, &bflag))) break;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { const int idx = lane + 64 * e; ou[e] = ld_agent(xu + (idx < n ? idx : n - 1)); }
+        const float vn = coop_update<EPT, false>(ccol, ou, n, lane, vj, eps, inv_eps, log_w);
+        vj = vn;
+        if (lane == 0 && live) {
+            xv[line] = vn;
+            if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + line] = vn;
+        }
+        if (!(ok = grid_barrier(a.ctrl, p, nwg, ++phase, &bflag))) break;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { const int idx = lane + 64 * e; ov[e] = ld_agent(xv + (idx < n ? idx : n - 1)); }
+        nits = it + 1;
+        // gan_utils.py:157-160 (count-based) / :115-117 (index-based); every workgroup sums the same partials
+        const bool reached = (a.stop_mode == KCCOT_STOP_INDEX) ? (it >= a.Lmin) : (nits >= a.Lmin);
+        if (reached && it + 1 < a.L) {
+            float err = 0.f;
+            for (unsigned k = 0; k < nwg; ++k) err += ld_agent(errp + (it & 1) * SC_MAXWG + k);
+            if (a.thresh > err) break;
+        }
+    }
+    // gan_utils.py:162-164: pi = exp((-C + u + v^T)/eps); cost = sum(pi * C)
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = lane + 64 * e;
+        if (live && idx < n) {
+            const float pi = __builtin_amdgcn_exp2f(((-crow[e] + ui) + ov[e]) * inv_eps * SC_LOG2E);
+            part += pi * crow[e];
+            if (a.pi_out) a.pi_out[(int64_t)p * n * n + (int64_t)line * n + idx] = pi;
+        }
+    }
+    part = wave_sum_fast(part);
+    if (lane == 0) red[w] = part;
+    __syncthreads();
+    if (t == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < SC_LINES; ++k) s += red[k];
+        a.costp[p * SC_MAXWG + wg] = s;
+    }
+    grid_barrier(a.ctrl, p, nwg, ++phase, &bflag);
+    if (wg == 0 && t == 0) {
+        float s = 0.f;
+        for (unsigned k = 0; k < nwg; ++k) s += ld_agent(a.costp + p * SC_MAXWG + k);
+        a.cost_out[p] = ok ? s : NAN;      // an aborted solve (see grid_barrier) must not look like a result
+        a.nits_out[p] = nits;
+        a.nits_out[gridDim.y + p] = nits;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// reverse sweep (see sinkhorn.hip for the derivation; natural units as in sinkhorn_gen.hip)
+struct SinkCoopBwdArgs {
+    const float* C;
+    const float* u_hist;
+    const float* v_hist;
+    const int32_t* nits;
+    const float* gcost;
+    float* dC;       // [nprob][n][n]: row-layout part
+    float* dCT;      // [nprob][n][n]: column-layout part, transposed (added by add_transposed_batched)
+    int n, L;
+    float eps, inv_eps;
+    CoopCtrl* ctrl;
+    float* xgu;      // [nprob][n]
+    float* xgv;
+};
+
+template <int EPT>
+__global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_coop(SinkCoopBwdArgs a) {
+    __shared__ int bflag;
+    const int p = blockIdx.y, wg = blockIdx.x, n = a.n;
+    const unsigned nwg = gridDim.x;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int line = wg * SC_LINES + w;
+    const bool live = line < n;
+    const int lsafe = live ? line : n - 1;
+    const float* C = a.C + (int64_t)p * n * n;
+    float* xgu = a.xgu + (int64_t)p * n;
+    float* xgv = a.xgv + (int64_t)p * n;
+    const float eps = a.eps, inv_eps = a.inv_eps, g = a.gcost[p];
+    const int nits = a.nits[p];
+    const float* uh = a.u_hist + (int64_t)p * a.L * n;     // history index k holds (u_{k+1}, v_{k+1}); u_0 = v_0 = 0
+    const float* vh = a.v_hist + (int64_t)p * a.L * n;
+    const float aconst = eps * logf(1.0f / (float)n);
+
+    float crow[EPT], ccol[EPT], drow[EPT], dcol[EPT];
+    int idxc[EPT];
+    bool okc[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = lane + 64 * e;
+        okc[e] = live && idx < n;
+        idxc[e] = idx < n ? idx : n - 1;
+        crow[e] = C[(int64_t)lsafe * n + idxc[e]];
+        ccol[e] = C[(int64_t)idxc[e] * n + lsafe];
+        drow[e] = 0.f; dcol[e] = 0.f;
+    }
+    auto hist = [&](const float* h, int it, int i) { return it >= 1 ? h[(int64_t)(it - 1) * n + i] : 0.f; };
+    // final-cost term: dC = g pi (1 - C/eps); gu = g sum_j pi C / eps; gv likewise
+    float gu_line, gv_line;
+    {
+        const float ui = hist(uh, nits, lsafe), vj = hist(vh, nits, lsafe);
+        float su = 0.f, sv = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const float vo = hist(vh, nits, idxc[e]), uo = hist(uh, nits, idxc[e]);
+            const float pr = okc[e] ? __builtin_amdgcn_exp2f(((-crow[e] + ui) + vo) * inv_eps * SC_LOG2E) : 0.f;
+            drow[e] = g * pr * (1.f - crow[e] * inv_eps);
+            su += pr * crow[e];
+            const float pc = okc[e] ? __builtin_amdgcn_exp2f(((-ccol[e] + uo) + vj) * inv_eps * SC_LOG2E) : 0.f;
+            sv += pc * ccol[e];
+        }
+        gu_line = g * wave_sum_fast(su) * inv_eps;
+        gv_line = g * wave_sum_fast(sv) * inv_eps;
+        if (lane == 0 && live) { xgu[line] = gu_line; xgv[line] = gv_line; }
+    }
+    unsigned phase = 0;
+    bool ok = grid_barrier(a.ctrl, p, nwg, ++phase, &bflag);
+    for (int it = nits; it >= 1 && ok; --it) {
+        // (A) row pass with Q_t: gu_i = [it == nits] gu_i - sum_j Q_ij gv_j ; dC_ij += Q_ij gv_j
+        {
+            const float ui = hist(uh, it, lsafe);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const float vo = hist(vh, it, idxc[e]);
+                const float gvj = ld_agent(xgv + idxc[e]);
+                const float qq = okc[e] ? __builtin_amdgcn_exp2f((((-crow[e] + ui) + vo) - aconst) * inv_eps * SC_LOG2E) : 0.f;
+                const float wv = qq * gvj;
+                drow[e] += wv;
+                s += wv;
+            }
+            s = wave_sum_fast(s);
+            gu_line = (it == nits ? gu_line : 0.f) - s;
+            if (lane == 0 && live) xgu[line] = gu_line;
+        }
+        if (!(ok = grid_barrier(a.ctrl, p, nwg, ++phase, &bflag))) break;
+        // (B) column pass with P_t: gv_j = -sum_i P_ij gu_i ; dC_ij += P_ij gu_i (kept in column layout)
+        {
+            const float vj = hist(vh, it - 1, lsafe);
+            float r = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const float uo = hist(uh, it, idxc[e]);
+                const float gui = ld_agent(xgu + idxc[e]);
+                const float pp = okc[e] ? __builtin_amdgcn_exp2f((((-ccol[e] + uo) + vj) - aconst) * inv_eps * SC_LOG2E) : 0.f;
+                const float wv = pp * gui;
+                dcol[e] += wv;
+                r += wv;
+            }
+            r = wave_sum_fast(r);
+            gv_line = -r;
+            if (lane == 0 && live) xgv[line] = gv_line;
+        }
+        ok = grid_barrier(a.ctrl, p, nwg, ++phase, &bflag);
+    }
+    float* dC = a.dC + (int64_t)p * n * n;
+    float* dCT = a.dCT + (int64_t)p * n * n;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        if (okc[e]) {
+            dC[(int64_t)line * n + idxc[e]] = drow[e];
+            dCT[(int64_t)line * n + idxc[e]] = dcol[e];      // row `line` of dC^T = column `line` of dC
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------
+size_t sinkhorn_gen_workspace_bytes(int nprob, int n);
+__global__ void add_transposed_batched(const float* __restrict__ in, float* __restrict__ out, int n);
+
+static bool coop_enabled() {
+    const char* e = getenv("KCCOT_SK_NO_COOP");      // =1: the single-workgroup streaming kernels (A/B, fallback)
+    return !(e && atoi(e) == 1);
+}
+
+bool sinkhorn_coop_eligible(int nprob, int n) {
+    const int nwg = (n + SC_LINES - 1) / SC_LINES;
+    return coop_enabled() && n > 128 && n <= 1024 && nprob <= 32 && nwg * nprob <= 192;   // all workgroups resident
+}
+
+struct CoopCarve { CoopCtrl* ctrl; float* x0; float* x1; float* e0; float* e1; float* second; };
+static CoopCarve coop_carve(void* ws, int nprob, int n) {
+    char* b = static_cast<char*>(ws);
+    CoopCarve c;
+    c.ctrl = reinterpret_cast<CoopCtrl*>(b);
+    float* f = reinterpret_cast<float*>(b + sizeof(CoopCtrl));
+    c.x0 = f; c.x1 = f + (size_t)nprob * n;
+    c.e0 = c.x1 + (size_t)nprob * n; c.e1 = c.e0 + (size_t)nprob * 2 * SC_MAXWG;
+    c.second = reinterpret_cast<float*>(b + sinkhorn_gen_workspace_bytes(nprob, n) / 2);
+    return c;
+}
+
+int launch_sinkhorn_fwd_coop(const float* C, int nprob, int n, float eps, int L, int Lmin, float thresh, int stop_mode,
+                             float* u_hist, float* v_hist, float* cost_out, int32_t* nits_out, float* pi_out, void* ws,
+                             hipStream_t st) {
+    const CoopCarve cv = coop_carve(ws, nprob, n);
+    if (hipMemsetAsync(cv.ctrl, 0, sizeof(CoopCtrl), st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_fwd(coop): memset failed");
+    SinkCoopArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
+                   cv.ctrl, cv.x0, cv.x1, cv.e0, cv.e1};
+    const dim3 grid((n + SC_LINES - 1) / SC_LINES, nprob);
+    const int ept = (n + 63) / 64;
+#define KCCOT_COOP(E) hipLaunchKernelGGL(sinkhorn_fwd_coop<E>, grid, dim3(SC_THREADS), 0, st, a)
+    if (ept <= 4) KCCOT_COOP(4); else if (ept <= 8) KCCOT_COOP(8); else KCCOT_COOP(16);
+#undef KCCOT_COOP
+    return launch_status("sinkhorn_fwd_coop");
+}
+
+int launch_sinkhorn_bwd_coop(const float* C, const float* u_hist, const float* v_hist, const int32_t* nits, int nprob, int n,
+                             float eps, int L, const float* gcost, float* dC, void* ws, hipStream_t st) {
+    const CoopCarve cv = coop_carve(ws, nprob, n);
+    if (hipMemsetAsync(cv.ctrl, 0, sizeof(CoopCtrl), st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_bwd(coop): memset failed");
+    SinkCoopBwdArgs a{C, u_hist, v_hist, nits, gcost, dC, cv.second, n, L, eps, (float)(1.0 / (double)eps), cv.ctrl, cv.x0, cv.x1};
+    const dim3 grid((n + SC_LINES - 1) / SC_LINES, nprob);
+    const int ept = (n + 63) / 64;
+#define KCCOT_COOP(E) hipLaunchKernelGGL(sinkhorn_bwd_coop<E>, grid, dim3(SC_THREADS), 0, st, a)
+    if (ept <= 4) KCCOT_COOP(4); else if (ept <= 8) KCCOT_COOP(8); else KCCOT_COOP(16);
+#undef KCCOT_COOP
+    int rc = launch_status("sinkhorn_bwd_coop");
+    if (rc) return rc;
+    dim3 tg((n + 31) / 32, (n + 31) / 32, nprob);
+    hipLaunchKernelGGL(add_transposed_batched, tg, dim3(256), 0, st, (const float*)cv.second, dC, n);
+    return launch_status("add_transposed_batched");
+}
+
+}  // namespace kccot

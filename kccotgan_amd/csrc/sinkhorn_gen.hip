@@ -478,12 +478,22 @@ size_t sinkhorn_gen_workspace_bytes(int nprob, int n) {
     return 2 * align_up((size_t)nprob * n * n * sizeof(float), 256);
 }
 
+// sinkhorn_coop.hip
+bool sinkhorn_coop_eligible(int nprob, int n);
+int launch_sinkhorn_fwd_coop(const float* C, int nprob, int n, float eps, int L, int Lmin, float thresh, int stop_mode,
+                             float* u_hist, float* v_hist, float* cost_out, int32_t* nits_out, float* pi_out, void* ws,
+                             hipStream_t st);
+int launch_sinkhorn_bwd_coop(const float* C, const float* u_hist, const float* v_hist, const int32_t* nits, int nprob, int n,
+                             float eps, int L, const float* gcost, float* dC, void* ws, hipStream_t st);
+
 int launch_sinkhorn_fwd_gen(const float* C, int nprob, int n, float eps, int L, int Lmin, float thresh, int stop_mode,
                             float* u_hist, float* v_hist, float* cost_out, int32_t* nits_out, float* pi_out, void* ws,
                             size_t ws_bytes, hipStream_t st) {
     if (n > SG_MAXN) return fail(KCCOT_EUNSUPPORTED, "sinkhorn_fwd: n=%d > %d", n, SG_MAXN);
     const size_t need = sinkhorn_gen_workspace_bytes(nprob, n);
     if (!ws || ws_bytes < need) return fail(KCCOT_EWORKSPACE, "sinkhorn_fwd: workspace %zu < required %zu", ws_bytes, need);
+    if (sinkhorn_coop_eligible(nprob, n))
+        return launch_sinkhorn_fwd_coop(C, nprob, n, eps, L, Lmin, thresh, stop_mode, u_hist, v_hist, cost_out, nits_out, pi_out, ws, st);
     float* CT = static_cast<float*>(ws);
     dim3 tg((n + 31) / 32, (n + 31) / 32, nprob);
     hipLaunchKernelGGL(transpose_batched, tg, dim3(256), 0, st, C, CT, n);
@@ -506,6 +516,8 @@ int launch_sinkhorn_bwd_gen(const float* C, const float* u_hist, const float* v_
     if (n > SG_MAXN) return fail(KCCOT_EUNSUPPORTED, "sinkhorn_bwd: n=%d > %d", n, SG_MAXN);
     const size_t need = sinkhorn_gen_workspace_bytes(nprob, n);
     if (!ws || ws_bytes < need) return fail(KCCOT_EWORKSPACE, "sinkhorn_bwd: workspace %zu < required %zu", ws_bytes, need);
+    if (sinkhorn_coop_eligible(nprob, n))
+        return launch_sinkhorn_bwd_coop(C, u_hist, v_hist, nits, nprob, n, eps, L, gcost, dC, ws, st);
     float* CT = static_cast<float*>(ws);
     float* dCT = reinterpret_cast<float*>(static_cast<char*>(ws) + need / 2);
     dim3 tg((n + 31) / 32, (n + 31) / 32, nprob);

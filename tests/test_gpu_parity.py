@@ -273,23 +273,55 @@ def test_sinkhorn_periodic_state_shortcut_is_bit_exact(G, L):
     assert skipped_somewhere      # the test must exercise the jump, not only the fall-through
 
 
-def test_sinkhorn_large_n_streaming_path(G, L):
-    """n > 128 (BASELINE configs 3-5 batch sizes): the streaming kernels, forward and reverse sweep,
+@pytest.mark.parametrize("solver", ["coop", "stream"])
+def test_sinkhorn_large_n_streaming_path(G, L, solver):
+    """n > 128 (BASELINE configs 3-5 batch sizes): the multi-CU cooperative solver (default) and the
+    single-workgroup streaming kernels it falls back to (KCCOT_SK_NO_COOP=1), forward and reverse sweep,
     against the oracle / fp64 autograd on random cost matrices."""
-    for n, Lc, eps in ((130, 25, 0.7), (256, 40, 1.0), (512, 12, 0.5)):
-        Cn = (np.random.default_rng(n).random((2, n, n), dtype=np.float32) * 6).astype(np.float32)
-        C = torch.from_numpy(Cn).to(DEV).requires_grad_(True)
-        cost = G._Sinkhorn.apply(C, eps, Lc, 100, L.STOP_COUNT, "large")
-        w = torch.tensor([1.0, -0.5], device=DEV)
-        (cost * w).sum().backward()
-        assert G.last_info["large"].tolist() == [Lc, Lc]
-        for p in range(2):
-            Cd = torch.from_numpy(Cn[p]).double().requires_grad_(True)
-            ref, nits = ot.sinkhorn_from_cost(Cd, eps, Lc)
-            ref.backward()
-            assert rel(cost[p], ref) < 2e-5, (n, p)
-            gref = Cd.grad.numpy() * float(w[p])
-            np.testing.assert_allclose(C.grad[p].cpu().numpy(), gref, rtol=0, atol=2e-4 * np.abs(gref).max())
+    if solver == "stream":
+        os.environ["KCCOT_SK_NO_COOP"] = "1"
+    try:
+        for n, Lc, eps in ((130, 25, 0.7), (256, 40, 1.0), (512, 12, 0.5)):
+            Cn = (np.random.default_rng(n).random((2, n, n), dtype=np.float32) * 6).astype(np.float32)
+            C = torch.from_numpy(Cn).to(DEV).requires_grad_(True)
+            cost = G._Sinkhorn.apply(C, eps, Lc, 100, L.STOP_COUNT, "large")
+            w = torch.tensor([1.0, -0.5], device=DEV)
+            (cost * w).sum().backward()
+            assert G.last_info["large"].tolist() == [Lc, Lc]
+            for p in range(2):
+                Cd = torch.from_numpy(Cn[p]).double().requires_grad_(True)
+                ref, nits = ot.sinkhorn_from_cost(Cd, eps, Lc)
+                ref.backward()
+                assert rel(cost[p], ref) < 2e-5, (n, p)
+                gref = Cd.grad.numpy() * float(w[p])
+                np.testing.assert_allclose(C.grad[p].cpu().numpy(), gref, rtol=0, atol=2e-4 * np.abs(gref).max())
+    finally:
+        os.environ.pop("KCCOT_SK_NO_COOP", None)
+
+
+def test_sinkhorn_cooperative_stop_rule_and_many_problems(G, L):
+    """The cooperative solver's stop rule (every workgroup sums the same per-workgroup partials) against the
+    streaming kernels: same executed iteration count and costs on a problem that stops early (L > Lmin); and
+    a launch with more problems than fit co-resident falls back to the streaming kernels on its own."""
+    n = 160
+    rng = np.random.default_rng(11)
+    Cn = (rng.random((3, n, n), dtype=np.float32) * 3).astype(np.float32)
+    C = torch.from_numpy(Cn).to(DEV)
+    res = {}
+    for solver in ("coop", "stream"):
+        if solver == "stream":
+            os.environ["KCCOT_SK_NO_COOP"] = "1"
+        try:
+            cost = G._Sinkhorn.apply(C, 1.0, 400, 100, L.STOP_COUNT, "stop")
+            res[solver] = (cost.cpu().numpy(), G.last_info["stop"].tolist())
+        finally:
+            os.environ.pop("KCCOT_SK_NO_COOP", None)
+    assert res["coop"][1] == res["stream"][1] and res["coop"][1][0] < 400
+    np.testing.assert_allclose(res["coop"][0], res["stream"][0], rtol=2e-5)
+    many = torch.from_numpy((rng.random((24, n, n), dtype=np.float32) * 3).astype(np.float32)).to(DEV)   # 24 x 10 workgroups > 192
+    cost = G._Sinkhorn.apply(many, 1.0, 30, 100, L.STOP_COUNT, "many")
+    ref = [o.sinkhorn_from_cost(many[p].cpu().numpy(), 1.0, 30)[0] for p in (0, 23)]
+    assert rel(cost[0], ref[0]) < 2e-5 and rel(cost[23], ref[1]) < 2e-5
 
 
 @pytest.mark.parametrize("B", [128, 256])
