@@ -20,13 +20,19 @@ namespace kccot {
 
 // ------------------------------------------------------------------------------------------
 // direct-difference partial tiles
-// block = 256 threads as 16 (ty) x 16 (tx); thread owns rows ty+16a, cols tx+16b (a,b < 4).
-// LDS tiles are [64][KT+4] floats: the +4 pitch makes the 16 rows a 16-lane ds_read_b128 group
+// block = 256 threads as 16 (ty) x 16 (tx); thread owns rows ty+16a (a < RA), cols tx+16b (b < 4) of a
+// (16 RA) x 64 output tile: RA = 8 for operands above 64 rows (12 ds_read_b128 feed 128 sub+fma pairs:
+// the LDS port stays below its 128 B/clk while the VALU runs packed), RA = 4, 2, 1 for 64 / 32 / 16 rows
+// (the row blocks of the batch-sharded caller), so that short operands do not pay for empty rows.
+// The k loop is packed two wide (v_pk_add_f32 / v_pk_fma_f32 on the .xy and .zw halves of the staged
+// float4s): the even and the odd k of a chunk accumulate separately and are added at the end.
+// LDS tiles are [rows][KT+4] floats: the +4 pitch makes the 16 rows a 16-lane ds_read_b128 group
 // touches land on 16 distinct 4-bank slots (36*r mod 64 is a permutation of multiples of 4).
 // ------------------------------------------------------------------------------------------
-constexpr int DT = 64;       // tile edge
+constexpr int DT = 64;       // tile width (columns); rows per tile = 16 * RA
 constexpr int DKT = 32;      // k-tile
 constexpr int DPITCH = DKT + 4;
+typedef float cost_f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float4 load4_guard(const float* __restrict__ row, int64_t k, int64_t kend,
                                               bool rowok, bool vec) {
@@ -40,9 +46,13 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ row, int
     return v;
 }
 
+template <int RA>
 __global__ __launch_bounds__(256) void cost_direct_partial(CostBatch cb, int64_t K, int64_t chunk,
                                                            int vec_ok) {
-    __shared__ __attribute__((aligned(16))) float xs[DT * DPITCH];
+    constexpr int TROWS = 16 * RA;
+    constexpr int NXL = (TROWS * 8 + 255) / 256;     // staged float4 per thread: x tile (4, 2, 1, 1) ...
+    constexpr int NYL = 2;                           // ... and y tile (64 rows x 8)
+    __shared__ __attribute__((aligned(16))) float xs[TROWS * DPITCH];
     __shared__ __attribute__((aligned(16))) float ys[DT * DPITCH];
 
     // decode (problem, tile_i, tile_j) from blockIdx.y
@@ -55,65 +65,79 @@ __global__ __launch_bounds__(256) void cost_direct_partial(CostBatch cb, int64_t
     if (p >= cb.nprob) return;
     const CostProb& pr = cb.p[p];
     const int ti = tile / pr.tiles_j, tj = tile % pr.tiles_j;
-    if (pr.same && tj < ti) return;  // mirrored by cost_finalize
-    const int i0 = ti * DT, j0 = tj * DT;
+    const int i0 = ti * TROWS, j0 = tj * DT;
+    // x == y problems: cost_finalize mirrors every 64-block below the block diagonal from above it, so a tile
+    // whose columns all lie in 64-blocks left of its first row's block is never read
+    if (pr.same && tj < i0 / DT) return;
     const int64_t kbeg = (int64_t)blockIdx.x * chunk;
     const int64_t kend = (kbeg + chunk < K) ? kbeg + chunk : K;
     if (kbeg >= kend) return;
 
     const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
     // staging assignment: float4 slot q = t + 256*m  ->  row q/8, column group q%8
-    const int srow0 = t >> 3, sc4 = (t & 7) * 4;
-    const float* xr0 = pr.x + (int64_t)(i0 + srow0) * K;
-    const float* xr1 = pr.x + (int64_t)(i0 + srow0 + 32) * K;
-    const float* yr0 = pr.y + (int64_t)(j0 + srow0) * K;
-    const float* yr1 = pr.y + (int64_t)(j0 + srow0 + 32) * K;
-    const bool xok0 = i0 + srow0 < pr.Bx, xok1 = i0 + srow0 + 32 < pr.Bx;
-    const bool yok0 = j0 + srow0 < pr.By, yok1 = j0 + srow0 + 32 < pr.By;
+    const int sc4 = (t & 7) * 4;
     const bool vec = vec_ok != 0;
-
-    float acc[4][4];
+    const float* xr[NXL];
+    bool xok[NXL];
+    int xrow[NXL];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int m = 0; m < NXL; ++m) {
+        xrow[m] = (t >> 3) + 32 * m;
+        xok[m] = xrow[m] < TROWS && i0 + xrow[m] < pr.Bx;
+        xr[m] = pr.x + (int64_t)(i0 + xrow[m]) * K;
+    }
+    const float* yr[NYL];
+    bool yok[NYL];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int m = 0; m < NYL; ++m) {
+        yok[m] = j0 + (t >> 3) + 32 * m < pr.By;
+        yr[m] = pr.y + (int64_t)(j0 + (t >> 3) + 32 * m) * K;
+    }
 
-    float4 nx0 = load4_guard(xr0, kbeg + sc4, kend, xok0, vec);
-    float4 nx1 = load4_guard(xr1, kbeg + sc4, kend, xok1, vec);
-    float4 ny0 = load4_guard(yr0, kbeg + sc4, kend, yok0, vec);
-    float4 ny1 = load4_guard(yr1, kbeg + sc4, kend, yok1, vec);
+    cost_f2 acc[RA][4];
+#pragma unroll
+    for (int a = 0; a < RA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = cost_f2{0.f, 0.f};
+
+    float4 nx[NXL], ny[NYL];
+#pragma unroll
+    for (int m = 0; m < NXL; ++m) nx[m] = load4_guard(xr[m], kbeg + sc4, kend, xok[m], vec);
+#pragma unroll
+    for (int m = 0; m < NYL; ++m) ny[m] = load4_guard(yr[m], kbeg + sc4, kend, yok[m], vec);
 
     for (int64_t k0 = kbeg; k0 < kend; k0 += DKT) {
-        *reinterpret_cast<float4*>(&xs[srow0 * DPITCH + sc4]) = nx0;
-        *reinterpret_cast<float4*>(&xs[(srow0 + 32) * DPITCH + sc4]) = nx1;
-        *reinterpret_cast<float4*>(&ys[srow0 * DPITCH + sc4]) = ny0;
-        *reinterpret_cast<float4*>(&ys[(srow0 + 32) * DPITCH + sc4]) = ny1;
+#pragma unroll
+        for (int m = 0; m < NXL; ++m)
+            if (xrow[m] < TROWS) *reinterpret_cast<float4*>(&xs[xrow[m] * DPITCH + sc4]) = nx[m];
+#pragma unroll
+        for (int m = 0; m < NYL; ++m) *reinterpret_cast<float4*>(&ys[((t >> 3) + 32 * m) * DPITCH + sc4]) = ny[m];
         __syncthreads();
         const int64_t kn = k0 + DKT;
         if (kn < kend) {  // prefetch the next k-tile while this one is consumed
-            nx0 = load4_guard(xr0, kn + sc4, kend, xok0, vec);
-            nx1 = load4_guard(xr1, kn + sc4, kend, xok1, vec);
-            ny0 = load4_guard(yr0, kn + sc4, kend, yok0, vec);
-            ny1 = load4_guard(yr1, kn + sc4, kend, yok1, vec);
+#pragma unroll
+            for (int m = 0; m < NXL; ++m) nx[m] = load4_guard(xr[m], kn + sc4, kend, xok[m], vec);
+#pragma unroll
+            for (int m = 0; m < NYL; ++m) ny[m] = load4_guard(yr[m], kn + sc4, kend, yok[m], vec);
         }
 #pragma unroll
         for (int kk = 0; kk < DKT; kk += 4) {
-            float4 xv[4], yv[4];
+            float4 xv[RA], yv[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < RA; ++a)
                 xv[a] = *reinterpret_cast<const float4*>(&xs[(ty + 16 * a) * DPITCH + kk]);
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 yv[b] = *reinterpret_cast<const float4*>(&ys[(tx + 16 * b) * DPITCH + kk]);
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < RA; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    float d;
-                    d = xv[a].x - yv[b].x; acc[a][b] = fmaf(d, d, acc[a][b]);
-                    d = xv[a].y - yv[b].y; acc[a][b] = fmaf(d, d, acc[a][b]);
-                    d = xv[a].z - yv[b].z; acc[a][b] = fmaf(d, d, acc[a][b]);
-                    d = xv[a].w - yv[b].w; acc[a][b] = fmaf(d, d, acc[a][b]);
+                    const cost_f2 xlo = {xv[a].x, xv[a].y}, xhi = {xv[a].z, xv[a].w};
+                    const cost_f2 ylo = {yv[b].x, yv[b].y}, yhi = {yv[b].z, yv[b].w};
+                    const cost_f2 d0 = xlo - ylo, d1 = xhi - yhi;
+                    acc[a][b] = __builtin_elementwise_fma(d0, d0, acc[a][b]);
+                    acc[a][b] = __builtin_elementwise_fma(d1, d1, acc[a][b]);
                 }
         }
         __syncthreads();
@@ -121,13 +145,13 @@ __global__ __launch_bounds__(256) void cost_direct_partial(CostBatch cb, int64_t
 
     float* part = pr.partial + (int64_t)blockIdx.x * pr.Bx * pr.By;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < RA; ++a) {
         const int i = i0 + ty + 16 * a;
         if (i >= pr.Bx) continue;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int j = j0 + tx + 16 * b;
-            if (j < pr.By) part[(int64_t)i * pr.By + j] = acc[a][b];
+            if (j < pr.By) part[(int64_t)i * pr.By + j] = acc[a][b].x + acc[a][b].y;
         }
     }
 }
@@ -163,14 +187,23 @@ __global__ __launch_bounds__(256) void cost_finalize(CostBatch cb, int nchunk, f
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// rows of a direct tile as a multiple of 16: 8 (128 rows) above 64-row operands, else the smallest of 4, 2, 1 that
+// covers the operand
+static int direct_ra(int nprob, const int* Bx) {
+    int mx = 0;
+    for (int p = 0; p < nprob; ++p) if (Bx[p] > mx) mx = Bx[p];
+    return mx > 64 ? 8 : mx > 32 ? 4 : mx > 16 ? 2 : 1;
+}
+
 static CostPlan plan_direct(int nprob, const int* Bx, const int* By, const int* same, int64_t K) {
     CostPlan pl{};
     pl.use_mfma = false;
     pl.tile = DT;
+    const int trows = 16 * direct_ra(nprob, Bx);
     int64_t ntiles = 0;
     for (int p = 0; p < nprob; ++p) {
-        const int ti = (Bx[p] + DT - 1) / DT, tj = (By[p] + DT - 1) / DT;
-        ntiles += same[p] ? (int64_t)ti * (ti + 1) / 2 : (int64_t)ti * tj;
+        const int ti = (Bx[p] + trows - 1) / trows, tj = (By[p] + DT - 1) / DT;
+        ntiles += same[p] ? ((int64_t)ti * tj + ti) / 2 + 1 : (int64_t)ti * tj;     // about half the tiles are skipped
     }
     const int64_t ksteps = (K + DKT - 1) / DKT;
     // ~4 workgroups per CU (18 KB LDS, <64 VGPRs each) so that staging latency is covered
@@ -196,11 +229,12 @@ static int run_direct(CostBatch& cb, int64_t K, float sc, int T, int J, void* ws
     CostPlan pl = plan_direct(cb.nprob, Bx, By, same, K);
     if (ws_bytes < pl.ws_bytes || !ws)
         return fail(KCCOT_EWORKSPACE, "pairwise_cost: workspace %zu < required %zu", ws_bytes, pl.ws_bytes);
+    const int ra = direct_ra(cb.nprob, Bx), trows = 16 * ra;
     int total_tiles = 0, max_bx = 0, max_by = 0;
     for (int p = 0; p < cb.nprob; ++p) {
         CostProb& pr = cb.p[p];
         pr.tile = DT;
-        pr.tiles_i = (pr.Bx + DT - 1) / DT;
+        pr.tiles_i = (pr.Bx + trows - 1) / trows;
         pr.tiles_j = (pr.By + DT - 1) / DT;
         pr.partial = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.partial_off[p]);
         total_tiles += pr.tiles_i * pr.tiles_j;
@@ -212,7 +246,10 @@ static int run_direct(CostBatch& cb, int64_t K, float sc, int T, int J, void* ws
     for (int p = 0; p < cb.nprob; ++p)
         vec = vec && (((uintptr_t)cb.p[p].x | (uintptr_t)cb.p[p].y) % 16 == 0);
     dim3 grid(pl.nchunk, total_tiles);
-    hipLaunchKernelGGL(cost_direct_partial, grid, dim3(256), 0, st, cb, K, pl.chunk, vec ? 1 : 0);
+    if (ra == 8) hipLaunchKernelGGL(cost_direct_partial<8>, grid, dim3(256), 0, st, cb, K, pl.chunk, vec ? 1 : 0);
+    else if (ra == 4) hipLaunchKernelGGL(cost_direct_partial<4>, grid, dim3(256), 0, st, cb, K, pl.chunk, vec ? 1 : 0);
+    else if (ra == 2) hipLaunchKernelGGL(cost_direct_partial<2>, grid, dim3(256), 0, st, cb, K, pl.chunk, vec ? 1 : 0);
+    else hipLaunchKernelGGL(cost_direct_partial<1>, grid, dim3(256), 0, st, cb, K, pl.chunk, vec ? 1 : 0);
     int rc = launch_status("cost_direct_partial");
     if (rc || partial_only) return rc;
     dim3 fgrid((max_by + CAUSAL_TILE - 1) / CAUSAL_TILE, (max_bx + CAUSAL_TILE - 1) / CAUSAL_TILE, cb.nprob);
