@@ -80,6 +80,16 @@ int kccot_pairwise_cost3_f32(const float* real, const float* fake, int B, int64_
                              unsigned flags, float* C3,
                              void* ws, size_t ws_bytes, kccot_stream_t stream);
 
+/* Row blocks [row_count, B] of the same three matrices for the batch-sharded caller (kccotgan_amd/dist.py: rank g
+ * owns samples [row_begin, row_begin+row_count) of the gathered batch): one launch of the exact direct-difference
+ * kernel over the three problems.  real / fake: gathered [B,K]; features: gathered [B,T,J]; C3_rows: [3,row_count,B].
+ * xx rows keep the reference's value for the i == j entries as computed ((x - x)^2 summed = 0 exactly). */
+size_t kccot_pairwise_cost3_rows_workspace_bytes(int row_count, int B, int64_t K);
+int kccot_pairwise_cost3_rows_f32(const float* real, const float* fake, int B, int64_t K, float sc,
+                                  const float* h_fake, const float* h_real, const float* m_real,
+                                  const float* m_fake, int T, int J, int row_begin, int row_count,
+                                  float* C3_rows, void* ws, size_t ws_bytes, kccot_stream_t stream);
+
 /* Backward of the three cost matrices: given g3 = dLoss/dC3 [3,B,B] writes
  *   dfake [B,K] (may be NULL), dh_fake, dh_real, dm_real, dm_fake [B,T,J] (each may be NULL).
  * real never receives a gradient (kernel_train.py:252,289). */

@@ -30,6 +30,8 @@ SIGNATURES = {
     "kccot_pairwise_cost_f32": (_i, [_fp, _fp, _i, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _u, _fp, _fp, _sz, _fp]),
     "kccot_pairwise_cost3_workspace_bytes": (_sz, [_i, _i64]),
     "kccot_pairwise_cost3_f32": (_i, [_fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _u, _fp, _fp, _sz, _fp]),
+    "kccot_pairwise_cost3_rows_workspace_bytes": (_sz, [_i, _i, _i64]),
+    "kccot_pairwise_cost3_rows_f32": (_i, [_fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _sz, _fp]),
     "kccot_pairwise_cost3_bwd_workspace_bytes": (_sz, [_i, _i64]),
     "kccot_pairwise_cost3_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i,
                                           _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),

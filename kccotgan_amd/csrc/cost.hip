@@ -336,3 +336,36 @@ extern "C" int kccot_pairwise_cost3_f32(const float* real, const float* fake, in
     cb.p[2] = CostProb{fake, fake, B, B, 1, h_fake, m_fake, nullptr, nullptr, C3 + 2 * bb, nullptr, 0, 0, 0};
     return run_cost(cb, true, K, sc, T, J, flags, ws, ws_bytes, (hipStream_t)stream);
 }
+
+// Row blocks [row_count, B] of the three cost matrices of compute_sinkhorn_loss for the batch-sharded caller
+// (rank g owns samples [row_begin, row_begin + row_count) of the gathered batch): ONE launch of the exact
+// direct-difference kernel over the three problems instead of three calls.  real / fake are the gathered [B,K]
+// tensors, the features the gathered [B,T,J] ones; C3_rows is [3, row_count, B].
+extern "C" size_t kccot_pairwise_cost3_rows_workspace_bytes(int row_count, int B, int64_t K) {
+    if (row_count <= 0 || B <= 0 || K <= 0) return 0;
+    int Bx[3] = {row_count, row_count, row_count}, By[3] = {B, B, B}, same[3] = {0, 0, 0};
+    return plan_direct(3, Bx, By, same, K).ws_bytes;
+}
+
+extern "C" int kccot_pairwise_cost3_rows_f32(const float* real, const float* fake, int B, int64_t K, float sc,
+                                             const float* h_fake, const float* h_real, const float* m_real,
+                                             const float* m_fake, int T, int J, int row_begin, int row_count,
+                                             float* C3_rows, void* ws, size_t ws_bytes, kccot_stream_t stream) {
+    if (!real || !fake || !C3_rows) return fail(KCCOT_EINVAL, "pairwise_cost3_rows: null pointer");
+    if (!h_fake || !h_real || !m_real || !m_fake) return fail(KCCOT_EINVAL, "pairwise_cost3_rows: all four feature tensors are needed");
+    if (B <= 0 || K <= 0 || T < 1 || J < 1 || row_begin < 0 || row_count <= 0 || row_begin + row_count > B)
+        return fail(KCCOT_EINVAL, "pairwise_cost3_rows: bad shape B=%d K=%lld rows [%d,%d)", B, (long long)K, row_begin,
+                    row_begin + row_count);
+    const int64_t rb = (int64_t)row_count * B, tj = (int64_t)T * J;
+    const float* xr = real + (int64_t)row_begin * K;
+    const float* yr = fake + (int64_t)row_begin * K;
+    const float* hf = h_fake + row_begin * tj;
+    const float* hr = h_real + row_begin * tj;
+    CostBatch cb{};
+    cb.nprob = 3;
+    // gan_utils.py:221-223, rows of this rank only (no x == y shortcut: a row block is not symmetric)
+    cb.p[0] = CostProb{xr, fake, row_count, B, 0, hf, m_real, nullptr, nullptr, C3_rows, nullptr, 0, 0, 0};
+    cb.p[1] = CostProb{xr, real, row_count, B, 0, hr, m_real, nullptr, nullptr, C3_rows + rb, nullptr, 0, 0, 0};
+    cb.p[2] = CostProb{yr, fake, row_count, B, 0, hf, m_fake, nullptr, nullptr, C3_rows + 2 * rb, nullptr, 0, 0, 0};
+    return run_cost(cb, false, K, sc, T, J, KCCOT_COST_FORCE_DIRECT, ws, ws_bytes, (hipStream_t)stream);
+}

@@ -50,6 +50,18 @@ class HipOps:
         return C
 
     @staticmethod
+    def cost3_rows(real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, row_count):
+        """Row blocks [3, row_count, B] of (xy, xx, yy) in one launch (kccot_pairwise_cost3_rows_f32)."""
+        B, K = real.shape
+        T, J = h_fake.shape[1], h_fake.shape[2]
+        out = _lib.empty((3, row_count, B), torch.float32, real.device)
+        ws, wsb = workspace(lib.kccot_pairwise_cost3_rows_workspace_bytes(row_count, B, K), real)
+        check(lib.kccot_pairwise_cost3_rows_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
+                                                ptr(m_fake), T, J, row_begin, row_count, ptr(out), ws, wsb,
+                                                stream_of(real)), "pairwise_cost3_rows")
+        return out
+
+    @staticmethod
     def sinkhorn3_fwd(C3, eps, L):
         nprob, n, _ = C3.shape
         dev = C3.device
@@ -137,9 +149,12 @@ class _ShardedLoss(torch.autograd.Function):
         feats = all_gather_cat(torch.stack([h_fake_l, h_real_l, m_real_l, m_fake_l], dim=1), group)
         h_fake, h_real, m_real, m_fake = (feats[:, i].contiguous() for i in range(4))
         # row blocks of the three cost matrices (gan_utils.py:221-223)
-        blk = torch.stack([ops.cost_rows(real_l, fake, h_fake_l, m_real, sc),
-                           ops.cost_rows(real_l, real, h_real_l, m_real, sc),
-                           ops.cost_rows(fake_l, fake, h_fake_l, m_fake, sc)], dim=0)            # [3,Bl,B]
+        if hasattr(ops, "cost3_rows"):       # one launch for the three row blocks
+            blk = ops.cost3_rows(real, fake, h_fake, h_real, m_real, m_fake, sc, rank * Bl, Bl)
+        else:
+            blk = torch.stack([ops.cost_rows(real_l, fake, h_fake_l, m_real, sc),
+                               ops.cost_rows(real_l, real, h_real_l, m_real, sc),
+                               ops.cost_rows(fake_l, fake, h_fake_l, m_fake, sc)], dim=0)        # [3,Bl,B]
         C3 = all_gather_cat(blk.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()  # [3,B,B]
         cost3, saved = ops.sinkhorn3_fwd(C3, eps, L)
         if ops is HipOps:
