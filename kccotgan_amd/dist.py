@@ -87,6 +87,40 @@ class HipOps:
         return dC3
 
     @staticmethod
+    def divergence_fwd(C3, eps, L):
+        """The three solves AND 2 xy - xx - yy in one launch (n <= 128; larger n: two launches inside the library)."""
+        from .gan_utils import _ticket
+        _, n, _ = C3.shape
+        dev = C3.device
+        Lh = max(int(L), 1)
+        u_hist = _lib.empty((3, Lh, n), torch.float32, dev)
+        v_hist = _lib.empty((3, Lh, n), torch.float32, dev)
+        small = _lib.empty((4,), torch.float32, dev)             # cost3 | loss
+        nits = _lib.empty((6,), torch.int32, dev)
+        ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(3, n), C3)
+        check(lib.kccot_sinkhorn_divergence_fwd_f32(ptr(C3), n, float(eps), int(L), _LMIN, _THRESH, ptr(u_hist), ptr(v_hist),
+                                                    ptr(small), ptr(nits), ptr(small[3:]), ptr(_ticket(dev)), ws, wsb,
+                                                    stream_of(C3)), "sinkhorn_divergence_fwd")
+        return small[3:].reshape(()), (C3, u_hist, v_hist, nits, float(eps), Lh)
+
+    @staticmethod
+    def divergence_bwd(saved, g):
+        C3, u_hist, v_hist, nits, eps, Lh = saved
+        _, n, _ = C3.shape
+        g = g.reshape(1).contiguous().float()
+        dC3 = _lib.empty_like(C3)
+        ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(3, n), C3)
+        if n > 128:      # streaming / cooperative solvers: weights first, then the generic reverse sweep
+            gc = _lib.empty((3,), torch.float32, g.device)
+            check(lib.kccot_mixed_divergence_bwd_f32(ptr(g), ptr(gc), stream_of(g)), "mixed_divergence_bwd")
+            check(lib.kccot_sinkhorn_bwd_f32(ptr(C3), ptr(u_hist), ptr(v_hist), ptr(nits), 3, n, eps, Lh, ptr(gc), ptr(dC3),
+                                             ws, wsb, stream_of(C3)), "sinkhorn_bwd")
+        else:
+            check(lib.kccot_sinkhorn_divergence_bwd_f32(ptr(C3), ptr(u_hist), ptr(v_hist), ptr(nits), n, eps, Lh, ptr(g),
+                                                        ptr(dC3), ws, wsb, stream_of(C3)), "sinkhorn_divergence_bwd")
+        return dC3
+
+    @staticmethod
     def cost3_bwd_rows(dC3, real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, row_count):
         B, K = real.shape
         T, J = h_fake.shape[1], h_fake.shape[2]
@@ -156,12 +190,16 @@ class _ShardedLoss(torch.autograd.Function):
                                ops.cost_rows(real_l, real, h_real_l, m_real, sc),
                                ops.cost_rows(fake_l, fake, h_fake_l, m_fake, sc)], dim=0)        # [3,Bl,B]
         C3 = all_gather_cat(blk.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()  # [3,B,B]
-        cost3, saved = ops.sinkhorn3_fwd(C3, eps, L)
+        if hasattr(ops, "divergence_fwd"):       # solves + combination in one launch
+            loss, saved = ops.divergence_fwd(C3, eps, L)
+        else:
+            cost3, saved = ops.sinkhorn3_fwd(C3, eps, L)
+            loss = (2.0 * cost3[0] - cost3[1]) - cost3[2]       # gan_utils.py:225
         if ops is HipOps:
             last_info["nits"], last_info["nits_executed"] = saved[3][:3], saved[3][3:]
         ctx.saved_state = (saved, real, fake, h_fake, h_real, m_real, m_fake)
         ctx.cfg = (sc, rank * Bl, Bl, ops)
-        return (2.0 * cost3[0] - cost3[1]) - cost3[2]           # gan_utils.py:225
+        return loss
 
     @staticmethod
     def backward(ctx, g):
@@ -170,8 +208,11 @@ class _ShardedLoss(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("the loss path never differentiates w.r.t. real (kernel_train.py:252,289)")
         g = g.reshape(())
-        gcost3 = torch.stack([2.0 * g, -g, -g])                 # d(2 xy - xx - yy)
-        dC3 = ops.sinkhorn3_bwd(saved, gcost3)
+        if hasattr(ops, "divergence_bwd"):
+            dC3 = ops.divergence_bwd(saved, g)
+        else:
+            gcost3 = torch.stack([2.0 * g, -g, -g])             # d(2 xy - xx - yy)
+            dC3 = ops.sinkhorn3_bwd(saved, gcost3)
         dfake, dhf, dhr, dmr, dmf = ops.cost3_bwd_rows(dC3, real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, Bl)
         return None, dfake, dhf, dhr, dmr, dmf, None, None, None, None, None
 
