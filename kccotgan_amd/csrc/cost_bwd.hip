@@ -16,13 +16,23 @@ namespace kccot {
 
 enum CoeffMode { CO_LOSS3_DFAKE = 0, CO_DX = 1, CO_DY = 2, CO_SAME = 3 };
 
+// exact three-way split of an fp32 value into bf16 pieces (the upper 16 bits of h, m, l): x = h + m + l
+__device__ __forceinline__ void split3u(float x, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned xb = __float_as_uint(x);
+    const float hf = __uint_as_float(xb & 0xFFFF0000u);
+    const float r1 = x - hf;                                               // exact
+    const float mf = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+    h = xb; m = __float_as_uint(r1); l = __float_as_uint(r1 - mf);         // pieces = the upper 16 bits of each word
+}
+
 // Wt is [R][Bout] (stack-row major) so that one output row block reads contiguous scalars.
 // R = n1 + n2 stack rows: first the n1 rows of src1, then the n2 rows of src2.
 // One block per output row m: thread r writes Wt[r][m]; the row / column sums that sit on the
 // diagonal are a block reduction (no serial loop).
+// W3 (optional): the same coefficients as three bf16 planes [3][Bout][R] for apply_coeffs_x3
 __device__ __forceinline__ void build_coeffs_body(int m, int mode, const float* __restrict__ g,
                                                   const float* __restrict__ g2, int Bx, int By, float sc,
-                                                  float* __restrict__ Wt) {
+                                                  float* __restrict__ Wt, unsigned short* __restrict__ W3 = nullptr) {
     // g: [Bx,By] (LOSS3: gxy [B,B]); g2: LOSS3 only: gyy [B,B]
     __shared__ float red[16];
     const int Bout = (mode == CO_DY) ? By : (mode == CO_LOSS3_DFAKE ? By : Bx);
@@ -64,6 +74,13 @@ __device__ __forceinline__ void build_coeffs_body(int m, int mode, const float* 
             if (r == m) w += two_sc * d;
         }
         Wt[(int64_t)r * Bout + m] = w;
+        if (W3) {
+            unsigned h, mm, l;
+            split3u(w, h, mm, l);
+            W3[((int64_t)0 * Bout + m) * R + r] = (unsigned short)(h >> 16);
+            W3[((int64_t)1 * Bout + m) * R + r] = (unsigned short)(mm >> 16);
+            W3[((int64_t)2 * Bout + m) * R + r] = (unsigned short)(l >> 16);
+        }
     }
 }
 
@@ -190,9 +207,9 @@ __global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, i
 __global__ __launch_bounds__(256) void coeffs_and_causal_grads(int mode, const float* __restrict__ g,
                                                                const float* __restrict__ g2, int Bx, int By, float sc,
                                                                float* __restrict__ Wt, int nbuild, CausalGradBatch cb,
-                                                               int T, int J, int gx, int gy) {
+                                                               int T, int J, int gx, int gy, unsigned short* __restrict__ W3) {
     if ((int)blockIdx.x < nbuild) {
-        build_coeffs_body(blockIdx.x, mode, g, g2, Bx, By, sc, Wt);
+        build_coeffs_body(blockIdx.x, mode, g, g2, Bx, By, sc, Wt, W3);
     } else {
         const int lin = blockIdx.x - nbuild;
         causal_grads_body(cb, T, J, sc, lin % gx, (lin / gx) % gy, lin / (gx * gy));
@@ -291,10 +308,162 @@ __global__ __launch_bounds__(256) void apply_coeffs_mfma(const float* __restrict
 }
 
 
+// ---- the same product on the bf16 matrix pipe, exactly -------------------------------------------------
+// The f32-input MFMA form above is bound by the matrix pipe (64 v_mfma_f32_32x32x2_f32 = 4096 pipe cycles per
+// wave and tile).  As in the Gram kernel, every fp32 value of W and of the video tile is cut EXACTLY into three
+// bf16 pieces (x = h + m + l) and the product is accumulated as hh + (hm + mh) + (hl + lh + mm) in fp32:
+// 48 v_mfma_f32_32x32x16_bf16 = 1536 pipe cycles per wave and tile, the dropped terms below 2^-24 |w z|.
+// Eight waves: 0-3 stage (load two adjacent stack rows x four columns, split, pack the row pair of each piece
+// into one dword and write it k-contiguous: LDS plane [column][stack row]), 4-7 own one 32x32 output sub-tile
+// each, keep their W fragments (8 k-steps x 3 pieces) in registers and read the tile's fragments as two
+// ds_read_b64 per piece and step.  Two LDS buffers, one barrier per tile.
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+constexpr int AX_COLP = AM_ROWS * 2 + 8;         // 264 bytes per column of a plane: conflict-free b64 reads, 8-byte aligned
+constexpr int AX_PLANE = AM_COLS * AX_COLP;      // 16896
+constexpr int AX_BUF = 3 * AX_PLANE;             // 50688
+
+// W3[(piece * Bout + m) * R + r] = piece of Wt[r * wpitch + m]   (bf16 bits; stack rows contiguous per output row)
+__global__ __launch_bounds__(256) void split_coeffs(const float* __restrict__ Wt, int wpitch, int R, int Bout,
+                                                    unsigned short* __restrict__ W3) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= R * Bout) return;
+    const int m = e / R, r = e % R;
+    unsigned h, mm, l;
+    split3u(Wt[(int64_t)r * wpitch + m], h, mm, l);
+    W3[((int64_t)0 * Bout + m) * R + r] = (unsigned short)(h >> 16);
+    W3[((int64_t)1 * Bout + m) * R + r] = (unsigned short)(mm >> 16);
+    W3[((int64_t)2 * Bout + m) * R + r] = (unsigned short)(l >> 16);
+}
+
+// out[bo x 64-column tile] (+)= W[bo x rr] * Z[rr x 64]: W3 planes hold ALL output rows / stack rows of the
+// problem (Bt x Rt); this launch uses output rows [0, bo) of the block W3 points at and stack rows [r0, r0 + rr).
+__global__ __launch_bounds__(512) void apply_coeffs_x3(const unsigned short* __restrict__ W3, int Bt, int Rt, int r0,
+                                                       const float* __restrict__ src1, int n1,
+                                                       const float* __restrict__ src2, int n2, int bo, int64_t K,
+                                                       int64_t ntiles, float* __restrict__ out, int accumulate) {
+    __shared__ __attribute__((aligned(16))) unsigned char zs[2 * AX_BUF];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int rr = n1 + n2;                       // stack rows of this chunk (multiple of 16, <= 128)
+    if (wave < 4) {
+        // ---------------------------------------------------------------- producers
+        const int c4 = (t & 15) * 4, rp0 = t >> 4;            // column group, first row pair
+        const float* rowp[8];
+        bool rowok[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 2 * (rp0 + 16 * (j >> 1)) + (j & 1);
+            rowok[j] = r < rr;
+            rowp[j] = r < n1 ? src1 + (int64_t)r * K : src2 + (int64_t)(r - n1) * K;
+        }
+        float4 v[8];
+        auto load_tile = [&](int64_t tile) {
+            const int64_t col = tile * AM_COLS + c4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = (rowok[j] && col + 4 <= K) ? *reinterpret_cast<const float4*>(rowp[j] + col)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        int64_t tile = blockIdx.x;
+        if (tile < ntiles) load_tile(tile);
+        int buf = 0;
+        for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+            unsigned char* zb = zs + buf * AX_BUF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * (rp0 + 16 * i);             // even stack row of the pair
+                const float a[4] = {v[2 * i].x, v[2 * i].y, v[2 * i].z, v[2 * i].w};
+                const float b[4] = {v[2 * i + 1].x, v[2 * i + 1].y, v[2 * i + 1].z, v[2 * i + 1].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned ha, ma, la, hb, mb, lb;
+                    split3u(a[c], ha, ma, la);
+                    split3u(b[c], hb, mb, lb);
+                    const int off = (c4 + c) * AX_COLP + r * 2;
+                    // dword = bf16(row r) | bf16(row r+1) << 16
+                    *reinterpret_cast<unsigned*>(zb + off) = __builtin_amdgcn_perm(hb, ha, 0x07060302u);
+                    *reinterpret_cast<unsigned*>(zb + AX_PLANE + off) = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
+                    *reinterpret_cast<unsigned*>(zb + 2 * AX_PLANE + off) = __builtin_amdgcn_perm(lb, la, 0x07060302u);
+                }
+            }
+            if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+            __syncthreads();
+        }
+        __syncthreads();          // the consumers' closing barrier
+        return;
+    }
+    // -------------------------------------------------------------------- consumers
+    const int w = wave - 4, mblk = w & 1, cblk = w >> 1;
+    const int nsteps = rr >> 4;
+    abf16x8 Ah[8], Am[8], Al[8];
+    {
+        int m = 32 * mblk + (lane & 31);
+        if (m >= bo) m = bo - 1;                              // rows past the block: any valid row (their outputs are not stored)
+        const unsigned short* wr = W3 + (int64_t)m * Rt + r0 + 8 * (lane >> 5);
+        const int64_t plane = (int64_t)Bt * Rt;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s < nsteps) {
+                Ah[s] = *reinterpret_cast<const abf16x8*>(wr + 16 * s);
+                Am[s] = *reinterpret_cast<const abf16x8*>(wr + plane + 16 * s);
+                Al[s] = *reinterpret_cast<const abf16x8*>(wr + 2 * plane + 16 * s);
+            }
+        }
+    }
+    const int boff = (32 * cblk + (lane & 31)) * AX_COLP + 16 * (lane >> 5);
+    int buf = 0;
+    __syncthreads();                                          // the first tile is staged
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const unsigned char* zb = zs + buf * AX_BUF;
+        const int64_t col = tile * AM_COLS + 32 * cblk + (lane & 31);
+        // later stack chunks add to the earlier ones' result: the old values are fetched under the MFMAs
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * mblk + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            acc[r] = (accumulate && col < K && m < bo) ? out[(int64_t)m * K + col] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s < nsteps) {
+                abf16x8 Bh, Bm, Bl;
+                uint2* ph = reinterpret_cast<uint2*>(&Bh);
+                uint2* pm = reinterpret_cast<uint2*>(&Bm);
+                uint2* pl = reinterpret_cast<uint2*>(&Bl);
+                ph[0] = *reinterpret_cast<const uint2*>(zb + boff + 32 * s);
+                ph[1] = *reinterpret_cast<const uint2*>(zb + boff + 32 * s + 8);
+                pm[0] = *reinterpret_cast<const uint2*>(zb + AX_PLANE + boff + 32 * s);
+                pm[1] = *reinterpret_cast<const uint2*>(zb + AX_PLANE + boff + 32 * s + 8);
+                pl[0] = *reinterpret_cast<const uint2*>(zb + 2 * AX_PLANE + boff + 32 * s);
+                pl[1] = *reinterpret_cast<const uint2*>(zb + 2 * AX_PLANE + boff + 32 * s + 8);
+                // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[s], Bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[s], Bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[s], Bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[s], Bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[s], Bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[s], Bh, acc, 0, 0, 0);
+            }
+        }
+        if (col < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * mblk + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < bo) out[(int64_t)m * K + col] = acc[r];
+            }
+        }
+        __syncthreads();                                      // this tile is consumed; the next one is staged
+    }
+}
+
 // Wt points at the first wanted output row's column; wpitch = full number of output rows of W
+// W3 (optional): the three bf16 planes of the SAME coefficients, [3][Bt][Rt] (split_coeffs), positioned at the first
+// wanted output row; selects the exact bf16 kernel when the stack is a multiple of 16 rows.
 static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, const float* s2, int n2, int Bout,
-                        int64_t K, float* out, hipStream_t st) {
+                        int64_t K, float* out, hipStream_t st, const unsigned short* W3 = nullptr, int Bt = 0, int Rt = 0) {
     const bool al = (K % 4 == 0) && ((uintptr_t)s1 % 16 == 0) && (n2 == 0 || (uintptr_t)s2 % 16 == 0);
+    const char* f32env = getenv("KCCOT_APPLY_F32");           // =1: the f32-input MFMA kernel (A/B and parity runs)
+    const bool x3 = al && W3 && (n1 + n2) % 16 == 0 && Rt % 8 == 0 && ((uintptr_t)W3 % 16 == 0) && !(f32env && atoi(f32env) == 1);
     if (al) {
         // MFMA kernel on blocks: 64 output rows x (up to) 128 stack rows at a time.  One block covers the
         // BASELINE configs[1] batch in a single launch; larger batches run (Bout/64) x (R/128) launches, the
@@ -317,6 +486,14 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
                 float* o = out + (int64_t)ob * K;
                 const int acc = r0 > 0;
                 const int rr = r1 - r0;
+                if (x3) {
+                    const unsigned gx3 = (unsigned)(ntiles < 256 ? ntiles : 256);     // 101 KB of LDS: one workgroup per CU
+                    hipLaunchKernelGGL(apply_coeffs_x3, dim3(gx3), dim3(512), 0, st, W3 + (int64_t)ob * Rt, Bt, Rt, r0, p1, m1, p2, m2,
+                                       bo, K, ntiles, o, acc);
+                    const int rc3 = launch_status("apply_coeffs_x3");
+                    if (rc3) return rc3;
+                    continue;
+                }
                 if (rr > 64) hipLaunchKernelGGL(apply_coeffs_mfma<64>, dim3(grid), dim3(256), 0, st, W, wpitch, p1, m1, p2, m2, bo, K, ntiles, o, acc);
                 else if (rr > 32) hipLaunchKernelGGL(apply_coeffs_mfma<32>, dim3(grid), dim3(256), 0, st, W, wpitch, p1, m1, p2, m2, bo, K, ntiles, o, acc);
                 else hipLaunchKernelGGL(apply_coeffs_mfma<16>, dim3(grid), dim3(256), 0, st, W, wpitch, p1, m1, p2, m2, bo, K, ntiles, o, acc);
@@ -341,7 +518,8 @@ using namespace kccot;
 extern "C" size_t kccot_pairwise_cost3_bwd_workspace_bytes(int B, int64_t K) {
     (void)K;
     if (B <= 0) return 0;
-    return align_up((size_t)2 * B * B * sizeof(float), 256);
+    // W [2B][B] f32, then its three bf16 planes [3][B][2B]
+    return align_up((size_t)2 * B * B * sizeof(float), 256) + align_up((size_t)3 * B * 2 * B * sizeof(unsigned short), 256);
 }
 
 extern "C" int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* real, const float* fake, int B,
@@ -373,16 +551,19 @@ extern "C" int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* r
     if (!ws || ws_bytes < need)
         return fail(KCCOT_EWORKSPACE, "pairwise_cost3_bwd: workspace %zu < required %zu", ws_bytes, need);
     float* Wt = static_cast<float*>(ws);
+    unsigned short* W3 = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + align_up((size_t)2 * B * B * sizeof(float), 256));
     if (cg.njobs == 0) {
         hipLaunchKernelGGL(build_coeffs, dim3(B), dim3(256), 0, st, (int)CO_LOSS3_DFAKE, gxy, gyy, B, B, sc, Wt);
         if ((rc = launch_status("build_coeffs"))) return rc;
+        hipLaunchKernelGGL(split_coeffs, dim3((2 * B * B + 255) / 256), dim3(256), 0, st, (const float*)Wt, B, 2 * B, B, W3);
+        if ((rc = launch_status("split_coeffs"))) return rc;
     } else {
         const int gx = (T * J + 15) / 16, gy = (row_count + 15) / 16;
         hipLaunchKernelGGL(coeffs_and_causal_grads, dim3(B + gx * gy * cg.njobs), dim3(256), 0, st, (int)CO_LOSS3_DFAKE,
-                           gxy, gyy, B, B, sc, Wt, B, cg, T, J, gx, gy);
+                           gxy, gyy, B, B, sc, Wt, B, cg, T, J, gx, gy, W3);
         if ((rc = launch_status("coeffs_and_causal_grads"))) return rc;
     }
-    return launch_apply(Wt + row_begin, B, real, B, fake, B, row_count, K, dfake, st);
+    return launch_apply(Wt + row_begin, B, real, B, fake, B, row_count, K, dfake, st, W3 + (int64_t)row_begin * 2 * B, B, 2 * B);
 }
 
 extern "C" int kccot_pairwise_cost3_bwd_f32(const float* g3, const float* real, const float* fake, int B,
