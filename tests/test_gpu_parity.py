@@ -673,3 +673,26 @@ def test_full_size_properties(G, shape):
     assert rel(loss2, loss) < 2e-5
     scale = float(g.abs().max())
     assert float((g2 - g[perm]).abs().max()) < 2e-3 * scale
+
+
+def test_video_gradient_bf16_split_matches_f32_mfma(G):
+    """dfake = W [X;Y] on the bf16 matrix pipe (exact three-way split of W and of the videos, the default) against
+    the f32-input MFMA kernel (KCCOT_APPLY_F32=1) at configs[1] full size and at a blocked batch (B = 128)."""
+    for shape in ((64, 64, 30, 64, 1), (128, 16, 10, 16, 3)):
+        B, H, T, W, C = shape
+        gen = torch.Generator(device=DEV).manual_seed(17 + B)
+        real = torch.rand(shape, device=DEV, generator=gen)
+        fake = (real + 0.05 * torch.randn(shape, device=DEV, generator=gen)).clamp_(0, 1)
+        f = {k: torch.rand((B, T, 8), device=DEV, generator=gen) for k in ("h_fake", "m_real", "h_real", "m_fake")}
+        grads = {}
+        for mode in ("x3", "f32"):
+            if mode == "f32":
+                os.environ["KCCOT_APPLY_F32"] = "1"
+            try:
+                fk = fake.clone().requires_grad_(True)
+                loss = G.compute_sinkhorn_loss(real, fk, cases.SC, 0.8, 100, f["h_fake"], f["m_real"], f["h_real"], f["m_fake"])
+                (grads[mode],) = torch.autograd.grad(loss, fk)
+            finally:
+                os.environ.pop("KCCOT_APPLY_F32", None)
+        scale = float(grads["f32"].abs().max())
+        assert float((grads["x3"] - grads["f32"]).abs().max()) < 2e-6 * scale
