@@ -337,10 +337,11 @@ __global__ __launch_bounds__(256) void split_coeffs(const float* __restrict__ Wt
 
 // out[bo x 64-column tile] (+)= W[bo x rr] * Z[rr x 64]: W3 planes hold ALL output rows / stack rows of the
 // problem (Bt x Rt); this launch uses output rows [0, bo) of the block W3 points at and stack rows [r0, r0 + rr).
+template <bool ACCUM>
 __global__ __launch_bounds__(512) void apply_coeffs_x3(const unsigned short* __restrict__ W3, int Bt, int Rt, int r0,
                                                        const float* __restrict__ src1, int n1,
                                                        const float* __restrict__ src2, int n2, int bo, int64_t K,
-                                                       int64_t ntiles, float* __restrict__ out, int accumulate) {
+                                                       int64_t ntiles, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) unsigned char zs[2 * AX_BUF];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3(const unsigned short* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = 32 * mblk + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            acc[r] = (accumulate && col < K && m < bo) ? out[(int64_t)m * K + col] : 0.f;
+            acc[r] = (ACCUM && col < K && m < bo) ? out[(int64_t)m * K + col] : 0.f;
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -488,8 +489,10 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
                 const int rr = r1 - r0;
                 if (x3) {
                     const unsigned gx3 = (unsigned)(ntiles < 256 ? ntiles : 256);     // 101 KB of LDS: one workgroup per CU
-                    hipLaunchKernelGGL(apply_coeffs_x3, dim3(gx3), dim3(512), 0, st, W3 + (int64_t)ob * Rt, Bt, Rt, r0, p1, m1, p2, m2,
-                                       bo, K, ntiles, o, acc);
+                    if (acc) hipLaunchKernelGGL(apply_coeffs_x3<true>, dim3(gx3), dim3(512), 0, st, W3 + (int64_t)ob * Rt, Bt, Rt, r0, p1, m1,
+                                                p2, m2, bo, K, ntiles, o);
+                    else hipLaunchKernelGGL(apply_coeffs_x3<false>, dim3(gx3), dim3(512), 0, st, W3 + (int64_t)ob * Rt, Bt, Rt, r0, p1, m1,
+                                            p2, m2, bo, K, ntiles, o);
                     const int rc3 = launch_status("apply_coeffs_x3");
                     if (rc3) return rc3;
                     continue;
