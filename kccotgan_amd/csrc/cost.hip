@@ -274,6 +274,8 @@ static int run_cost(CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J
     }
     const bool partial_only = (flags & KCCOT_COST_PARTIAL_ONLY) != 0;
     if (mfma) return run_gram(cb, loss3, K, sc, T, J, ws, ws_bytes, partial_only, st);
+    if (!(flags & KCCOT_COST_FORCE_DIRECT) && !partial_only && gram_blocked_eligible(cb, K, loss3))
+        return run_gram_blocked(cb, K, sc, T, J, ws, ws_bytes, st);
     return run_direct(cb, K, sc, T, J, ws, ws_bytes, partial_only, st);
 }
 

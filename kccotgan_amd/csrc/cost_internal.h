@@ -17,6 +17,11 @@ struct CostProb {
     float* out;       // [Bx,By]
     float* partial;   // direct path: [nchunk,Bx,By] partial sums of (x-y)^2
     int tile, tiles_i, tiles_j;
+    // blocked MFMA path (batches above 64): `out` is a block of a larger matrix with this row pitch (0 = By), and
+    // `out_t` (optional) receives the TRANSPOSED distances of the block plus the causal term of (h2 rows, M2 cols)
+    // -- the mirror block of an x == y problem, whose features differ from the block's own
+    int out_pitch;
+    float* out_t;
 };
 
 struct CostBatch {
@@ -114,5 +119,7 @@ bool gram_preferred(const CostBatch& cb, int64_t K, bool loss3);
 GramPlan plan_gram(int64_t K);
 int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J, void* ws,
              size_t ws_bytes, bool partial_only, hipStream_t st);
+bool gram_blocked_eligible(const CostBatch& cb, int64_t K, bool loss3);
+int run_gram_blocked(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace kccot

@@ -643,6 +643,8 @@ struct GramFin {
     const float* caus;   // [3][B1][B2] causal sums written by gram_reduce's extra workgroups: slot p for h[p]; slot 1 for h2
     float sc;
     int T, J;
+    int pitch;           // row pitch of the outputs (blocks of a larger matrix), >= B2
+    float* out_t;        // GRAM_XY only: blockIdx.z == 1 writes the transposed distances + the (h2, M2) causal term here
 };
 
 __device__ __forceinline__ double gram_at(const double* __restrict__ gsum, int s, int t) {
@@ -662,8 +664,8 @@ __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
     // all Gram entries are fetched up front (no control flow between the loads: one memory round trip)
     const int ii = ok ? i : 0, jj = ok ? j : 0;
     const int64_t plane = (int64_t)f.B1 * f.B2, at = (int64_t)ii * f.B2 + jj;
-    const float ca = f.h[p] ? f.caus[p * plane + at] : 0.f;
-    const float cb = (p == 0 && f.h2) ? f.caus[plane + at] : 0.f;
+    const float ca = (f.h[f.out_t ? 0 : p]) ? f.caus[(f.out_t ? 0 : p) * plane + at] : 0.f;
+    const float cb = (p == 0 && f.h2 && !f.out_t) ? f.caus[plane + at] : 0.f;
     double D;
     if (f.mode == GRAM_LOSS3) {
         const double g_ii = gram_at(G, ii, ii), g_jj = gram_at(G, jj, jj), g_ij = gram_at(G, ii, jj);
@@ -684,9 +686,16 @@ __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
     }
     if (D < 0.0) D = 0.0;   // a squared distance; rounding of the Gram terms may leave -tiny
     float c = (float)D * f.sc;
+    if (f.out_t) {
+        // mirror block of an x == y problem (blocked path): blockIdx.z == 0 is the block itself with the (h, M) term,
+        // blockIdx.z == 1 its transpose with the (h2, M2) term (rows = this block's columns)
+        if (p == 0) { if (f.h[0]) c += ca * f.sc; if (ok) f.out[0][(int64_t)i * f.pitch + j] = c; }
+        else { if (f.h2) c += f.caus[plane + (int64_t)jj * f.B2 + ii] * f.sc; if (ok) f.out_t[(int64_t)j * f.pitch + i] = c; }
+        return;
+    }
     if (f.h[p]) c += ca * f.sc;
     if (p == 0 && f.h2) c += cb * f.sc;
-    if (ok) f.out[p][(int64_t)i * f.B2 + j] = c;
+    if (ok) f.out[p][(int64_t)i * f.pitch + j] = c;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -778,12 +787,16 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
         gf.B1 = gf.B2 = p0.Bx;
         gf.out[0] = p0.out; gf.h[0] = p0.h1; gf.M[0] = p0.M1; gf.h2 = p0.h2; gf.M2 = p0.M2;
     } else {
-        mode = GRAM_XY; nout = 1;
+        mode = GRAM_XY; nout = p0.out_t ? 2 : 1;
         ga.src1 = p0.x; ga.src2 = p0.y; ga.n1 = p0.Bx; ga.n2 = p0.By; ga.pair_diff = 0;
         gf.B1 = p0.Bx; gf.B2 = p0.By;
         gf.out[0] = p0.out; gf.h[0] = p0.h1; gf.M[0] = p0.M1; gf.h2 = p0.h2; gf.M2 = p0.M2;
+        gf.out_t = p0.out_t;
     }
+    gf.pitch = p0.out_pitch > 0 ? p0.out_pitch : gf.B2;
     ga.mask = gram_mask(mode, ga.n1, ga.n2);
+    // full 64 + 64 stacks: the bf16 kernel computes all ten sub-tiles (two more than a plain x-y problem reads)
+    if (mode == GRAM_XY && ga.n1 == 64 && ga.n2 == 64 && gram_use_x3()) ga.mask = 0x3FFu;
     ga.K = K; ga.chunk = pl.chunk;
     ga.gpart = static_cast<float*>(ws);
     double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.gpart_bytes);
@@ -827,6 +840,71 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     hipLaunchKernelGGL(gram_finalize, dim3((gf.B2 + CAUSAL_TILE - 1) / CAUSAL_TILE, (gf.B1 + CAUSAL_TILE - 1) / CAUSAL_TILE, nout),
                        dim3(256), 0, st, gf);
     return launch_status("gram_finalize");
+}
+
+}  // namespace kccot
+
+namespace kccot {
+
+// ---- batches above 64: the loss's three matrices in 64 x 64 blocks -----------------------------------------
+// Diagonal blocks (I,I) carry the entries the pair-difference form exists for (sample i against its own fake):
+// they run the GRAM_LOSS3 kernel on (real_I, fake_I).  Off-diagonal blocks compare different samples -- distances
+// of the size of the operands' norms, where the plain Gram form x.x + y.y - 2 x.y (exact bf16 split, fp64
+// combination) is accurate -- and run the GRAM_XY kernel on a [rows_I ; cols_J] stack: xy needs both (I,J) and
+// (J,I); xx and yy are symmetric in their distances, so one launch per unordered pair writes the block and, with
+// the mirror block's own causal term, its transpose.  nb + 2 nb (nb - 1) launches of three kernels each.
+bool gram_blocked_eligible(const CostBatch& cb, int64_t K, bool loss3) {
+    if (!loss3 || cb.nprob != 3 || !gram_use_x3() || getenv("KCCOT_COST_NO_BLOCKED")) return false;
+    const int B = cb.p[0].Bx;
+    if (B <= 64 || B % 64 != 0 || cb.p[0].By != B || K % 4 != 0 || K < 256) return false;
+    for (int p = 0; p < 3; ++p)
+        if ((uintptr_t)cb.p[p].x % 16 || (uintptr_t)cb.p[p].y % 16) return false;
+    return true;
+}
+
+int run_gram_blocked(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int B = cb.p[0].Bx, nb = B / 64;
+    const float* real = cb.p[0].x;
+    const float* fake = cb.p[0].y;
+    const int64_t tj = (int64_t)T * J;
+    auto rows = [&](const float* v, int blk) { return v + (int64_t)blk * 64 * K; };
+    auto feat = [&](const float* f, int blk) { return f ? f + (int64_t)blk * 64 * tj : nullptr; };
+    auto block = [&](float* out, int I, int Jb) { return out + (int64_t)I * 64 * B + (int64_t)Jb * 64; };
+    int rc;
+    for (int I = 0; I < nb; ++I) {
+        // diagonal block: the pair-difference kernel, three outputs
+        CostBatch d{};
+        d.nprob = 3;
+        for (int p = 0; p < 3; ++p) {
+            d.p[p] = cb.p[p];
+            d.p[p].x = rows(cb.p[p].x, I); d.p[p].y = rows(cb.p[p].y, I);
+            d.p[p].Bx = d.p[p].By = 64;
+            d.p[p].h1 = feat(cb.p[p].h1, I); d.p[p].M1 = feat(cb.p[p].M1, I);
+            d.p[p].out = block(cb.p[p].out, I, I); d.p[p].out_pitch = B;
+        }
+        if ((rc = run_gram(d, true, K, sc, T, J, ws, ws_bytes, false, st))) return rc;
+        for (int Jb = 0; Jb < nb; ++Jb) {
+            if (Jb == I) continue;
+            // xy block (I,J): real rows I against fake rows J, features of problem 0
+            CostBatch o{};
+            o.nprob = 1;
+            o.p[0] = CostProb{rows(real, I), rows(fake, Jb), 64, 64, 0, feat(cb.p[0].h1, I), feat(cb.p[0].M1, Jb), nullptr, nullptr,
+                              block(cb.p[0].out, I, Jb), nullptr, 0, 0, 0, B, nullptr};
+            if ((rc = run_gram(o, false, K, sc, T, J, ws, ws_bytes, false, st))) return rc;
+            if (Jb < I) continue;
+            // xx and yy blocks (I,J) and their mirrors (J,I): one launch per unordered pair
+            for (int p = 1; p <= 2; ++p) {
+                const float* v = p == 1 ? real : fake;
+                CostBatch m{};
+                m.nprob = 1;
+                m.p[0] = CostProb{rows(v, I), rows(v, Jb), 64, 64, 0, feat(cb.p[p].h1, I), feat(cb.p[p].M1, Jb),
+                                  feat(cb.p[p].h1, Jb), feat(cb.p[p].M1, I), block(cb.p[p].out, I, Jb), nullptr, 0, 0, 0, B,
+                                  block(cb.p[p].out, Jb, I)};
+                if ((rc = run_gram(m, false, K, sc, T, J, ws, ws_bytes, false, st))) return rc;
+            }
+        }
+    }
+    return 0;
 }
 
 }  // namespace kccot

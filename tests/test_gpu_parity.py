@@ -324,6 +324,41 @@ def test_sinkhorn_cooperative_stop_rule_and_many_problems(G, L):
     assert rel(cost[0], ref[0]) < 2e-5 and rel(cost[23], ref[1]) < 2e-5
 
 
+@pytest.mark.parametrize("B,regime", [(128, "near"), (192, "far"), (256, "near")])
+def test_cost3_blocked_mfma_path_above_64(G, L, B, regime):
+    """Batches above 64 (multiples of 64, K >= 256): the three matrices are assembled from 64 x 64 blocks on the
+    MFMA kernels -- pair-difference form on the diagonal blocks, plain Gram form off the diagonal, mirrored blocks
+    for the x == y problems.  Checked against the f64 oracle and against the direct-difference kernel."""
+    rng = np.random.default_rng(1000 + B)
+    H, T, W, Cc, J = 8, 10, 8, 4, 8
+    real = rng.random((B, H, T, W, Cc), dtype=np.float32)
+    if regime == "near":
+        fake = np.clip(real + np.float32(0.01) * rng.standard_normal(real.shape, dtype=np.float32), 0, 1).astype(np.float32)
+    else:
+        fake = rng.random(real.shape, dtype=np.float32)
+    f = {k: rng.random((B, T, J), dtype=np.float32) for k in ("h_fake", "m_real", "h_real", "m_fake")}
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in dict(real=real, fake=fake, **f).items()}
+    args = (t["real"].reshape(B, -1), t["fake"].reshape(B, -1), t["h_fake"], t["h_real"], t["m_real"], t["m_fake"], cases.SC)
+    G.cost_flags = 0
+    blocked = G._Cost3.apply(*args).cpu().numpy()
+    G.cost_flags = L.COST_FORCE_DIRECT
+    direct = G._Cost3.apply(*args).cpu().numpy()
+    x64, y64 = real.reshape(B, -1).astype(np.float64), fake.reshape(B, -1).astype(np.float64)
+    pairs = {"xy": (x64, y64, "h_fake", "m_real"), "xx": (x64, x64, "h_real", "m_real"), "yy": (y64, y64, "h_fake", "m_fake")}
+    for k, tag in enumerate(("xy", "xx", "yy")):
+        a, b, hk, mk = pairs[tag]
+        l2 = ((a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2 * a @ b.T)
+        if tag == "xy":
+            l2[np.arange(B), np.arange(B)] = ((a - b) ** 2).sum(1)
+        else:
+            l2[np.arange(B), np.arange(B)] = 0.0
+        ref = l2 * cases.SC + o.causal_term(f[hk], f[mk], cases.SC, dtype=np.float64)
+        np.testing.assert_allclose(blocked[k], ref, rtol=0, atol=1e-5 * np.abs(ref).max(), err_msg=tag)
+        np.testing.assert_allclose(blocked[k], direct[k], rtol=0, atol=1e-5 * np.abs(ref).max(), err_msg=tag + " vs direct")
+        # the sample-against-its-own-fake entries are the small ones: relative accuracy there
+        np.testing.assert_allclose(np.diag(blocked[k]), np.diag(ref), rtol=2e-5, atol=1e-7, err_msg=tag + " diagonal")
+
+
 @pytest.mark.parametrize("B", [128, 256])
 def test_loss_at_larger_batches(G, B):
     """configs 3/4 batch sizes (decimated frames so that the CPU oracle finishes in seconds): direct

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""RCCL plumbing check on a one-GPU box: world_size 1 over the nccl backend (two ranks cannot share a card under
+RCCL).  Exercises exactly the calls bench.py / kccotgan_amd.dist make at N > 1 -- init_process_group with a
+device id, all_gather_into_tensor / all_reduce(MAX) / barrier on device tensors -- and one sharded loss step.
+Launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 tools/nccl_selftest.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29511")
+os.environ.setdefault("RANK", "0")
+os.environ.setdefault("WORLD_SIZE", "1")
+dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+x = torch.arange(12, dtype=torch.float32, device=dev).reshape(3, 4)
+out = torch.empty((dist.get_world_size() * 3, 4), device=dev)
+dist.all_gather_into_tensor(out, x)
+assert torch.equal(out, x)
+m = torch.tensor([3.5], dtype=torch.float64, device=dev)
+dist.all_reduce(m, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+from kccotgan_amd import dist as kd
+import bench
+inp, t = bench.make_inputs(bench.SHAPE["B"], 0, dev)
+for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
+    t[k].requires_grad_(True)
+shard = kd.shard_batch(t, 0, 1)
+loss, grads = kd.sharded_loss_step(shard, bench.SC)
+torch.cuda.synchronize()
+print("nccl selftest ok: backend=%s loss=%.6f" % (dist.get_backend(), float(loss)))
+dist.destroy_process_group()
