@@ -14,9 +14,15 @@ feeds its shard of the batch, the loss is the GLOBAL-batch divergence assembled 
 ``kccotgan_amd.dist`` and parameter gradients are all-reduced with SUM (the loss is replicated,
 each rank holds the partial derivative through its own samples).
 
-Out of scope: the dataset loaders, CLI, logging and checkpoint code of
-``train(args)``.
+``sample`` is the test-time autoregressive loop (kernel_train.py:340-347), ``fit`` the loop body around the two
+steps (:295-330): per-iteration sigma (annealed or fixed, :308-311), the scalar log ``pM`` / ``Sinkhorn Loss``
+(:318-321), the non-finite-loss guard (:323-329) and the periodic sample (:331,338-355).  Batches come from
+``kccotgan_amd.datasets``.
+
+Out of scope: TFRecord readers, CLI, TensorBoard writers and weight files of ``train(args)``.
 """
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -142,6 +148,61 @@ class KCCOTTrainer:
         self.g_steps += 1
         self._apply(self.gen_optimiser, self.g_params, self.g_steps)             # :290-291
         return loss.detach()                                                     # :292
+
+    # ------------------------------------------------------------------ kernel_train.py:338-355
+    @torch.no_grad()
+    def sample(self, test_data):
+        """Autoregressive roll-out (kernel_train.py:340-347): keep the first ``int_time_steps`` frames of
+        ``test_data`` [B,H,T,W,C], then ``pred_time_steps`` times encode everything generated so far, draw ONE
+        latent frame z ~ N(0,1) of shape [B,1,z_h,z_w,z_channels] and decode with ``training=False`` (the decoder
+        reads only the last encoded frame, gan.py:269-272) and append the frame.  Returns [B,H,T_total,W,C]."""
+        test_inputs = test_data[:, :, :self.int_time_steps].to(self.device, torch.float32)
+        z_shape = (self.batch_size, 1) + tuple(self.z_shape[2:])
+        for _ in range(self.pred_time_steps):
+            preds_features = self.context_encoder(test_inputs, training=False)
+            hidden_z = torch.randn(z_shape, device=self.device)
+            preds = self.decoder(preds_features, hidden_z, training=False)
+            test_inputs = torch.cat((test_inputs, preds), dim=2)
+        return test_inputs
+
+    @staticmethod
+    def sample_image(videos, max_rows=10):
+        """kernel_train.py:349-351: [B,H,T,W,C] -> one image [1, min(10,B)*H, W*T, C], a row of frames per sample."""
+        B, H, T, W, C = videos.shape
+        images = videos.reshape(B, H, W * T, C)
+        return torch.cat(list(images[:min(max_rows, B)]), dim=0)[None]
+
+    def fit(self, batched_x, test_x=None, init_sigma=5.0, decaying_sigma=False, save_freq=500, log=None,
+            max_iterations=None):
+        """The loop body of kernel_train.py:295-355 over an iterable of [B,H,T,W,C] batches.
+
+        ``log(name, value, step)`` receives 'pM' and 'Sinkhorn Loss' every iteration (:318-321) and 'Training data'
+        (the sample image) at iteration 1 and every ``save_freq`` iterations when ``test_x`` (one [B,H,T,W,C] batch)
+        is given (:331,338-355).  A non-finite generator loss ends the run (:323-329).  Returns a dict with the
+        iteration count, the scalar history and ``exploded``."""
+        history = {"pM": [], "Sinkhorn Loss": []}
+        it_counts, exploded = 0, False
+        for x in batched_x:
+            if x.shape[0] != self.batch_size:                                    # :298-299
+                continue
+            it_counts += 1
+            real_data = x.to(self.device, torch.float32)
+            sig = (self.gaussian_kernel.annealing_sigma(init_sigma, it_counts) if decaying_sigma else init_sigma)  # :308-311
+            pm, loss = self.train_iteration(real_data, sig)
+            pm, loss = float(pm), float(loss)
+            history["pM"].append(pm)
+            history["Sinkhorn Loss"].append(loss)
+            if log is not None:
+                log("pM", pm, it_counts)
+                log("Sinkhorn Loss", loss, it_counts)
+            if not math.isfinite(loss):                                          # :323
+                exploded = True
+                break
+            if test_x is not None and (it_counts % save_freq == 0 or it_counts == 1) and log is not None:   # :331
+                log("Training data", self.sample_image(self.sample(test_x)), it_counts)
+            if max_iterations is not None and it_counts >= max_iterations:
+                break
+        return {"iterations": it_counts, "history": history, "exploded": exploded}
 
     def train_iteration(self, real_data, sigma=5.0):
         """One pass of the loop body kernel_train.py:301-314 on a [B,H,T,W,C] batch."""

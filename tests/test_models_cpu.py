@@ -57,3 +57,63 @@ def test_lr_schedule():
     assert abs(warmup_exponential_decay(10000, 5e-4) - 5e-4) < 1e-12
     assert abs(warmup_exponential_decay(14999, 5e-4) - 5e-4) < 1e-12
     assert abs(warmup_exponential_decay(15000, 5e-4) - 5e-4 * 0.975) < 1e-12
+
+
+# ---------------------------------------------------------------- SURVEY.md section 8 f3 / f4
+def _tiny_trainer(B=2, T=5, iT=2):
+    from kccotgan_amd.kernel_train import KCCOTTrainer
+    return KCCOTTrainer(B, total_time_steps=T, int_time_steps=iT, x_height=16, x_width=16, channels=1, g_state_size=4,
+                        d_state_size=4, g_filter_size=1, d_filter_size=1, z_channels=3, device="cpu", seed=3)
+
+
+def test_autoregressive_sampling_loop():
+    """kernel_train.py:340-351: the context frames are kept, one frame is appended per step, output in [0,1]."""
+    import numpy as np
+    tr = _tiny_trainer()
+    x = torch.rand(2, 16, 5, 16, 1)
+    out = tr.sample(x)
+    assert tuple(out.shape) == (2, 16, 5, 16, 1)
+    assert torch.equal(out[:, :, :2], x[:, :, :2])
+    assert float(out.min()) >= 0 and float(out.max()) <= 1
+    # each appended frame depends only on the frames before it: re-running the first step alone reproduces frame 2
+    torch.manual_seed(11)
+    a = tr.sample(x)
+    torch.manual_seed(11)
+    feats = tr.context_encoder(x[:, :, :2], training=False)
+    z = torch.randn(2, 1, 1, 1, 3)
+    first = tr.decoder(feats, z, training=False)
+    np.testing.assert_allclose(a[:, :, 2:3].numpy(), first.detach().numpy(), rtol=0, atol=1e-6)
+    img = tr.sample_image(out)
+    assert tuple(img.shape) == (1, 2 * 16, 16 * 5, 1)
+    # row b of the image is sample b with its frames side by side (tf.reshape of [B,H,T,W,C] to [B,H,W*T,C])
+    assert torch.equal(img[0, 16:32, 16:32, 0], out[1, :, 1, :, 0])
+
+
+def test_dataset_adapters_layouts():
+    import numpy as np
+    from kccotgan_amd import datasets as ds
+    rng = np.random.default_rng(0)
+    mm = rng.integers(0, 256, size=(7, 5, 8, 6), dtype=np.uint8)            # [T_all, N, H, W]
+    v = ds.mmnist_videos(mm, 4)
+    assert v.shape == (5, 8, 4, 6) and v.dtype == np.float64
+    for n, h, t, w in ((0, 0, 0, 0), (4, 7, 3, 5), (2, 3, 1, 4)):
+        assert v[n, h, t, w] == mm[t, n, h, w] / 255.0
+    mz = rng.random((3, 8, 9, 8, 3))
+    assert np.array_equal(ds.mazes_test_videos(mz, 4), mz[:, :, :4])
+    fr = rng.integers(0, 256, size=(6, 8, 8, 3), dtype=np.uint8)            # decoded frames [T,H,W,C]
+    vid = ds.frames_to_video(fr, 5)
+    assert vid.shape == (8, 5, 8, 3) and vid[3, 2, 4, 1] == fr[2, 3, 4, 1] / 255.0
+    got = list(ds.batches(v, 2, 8, 4, 6, 1, epochs=2))
+    assert len(got) == 4                                                      # 5 videos -> 2 full batches per epoch
+    assert all(tuple(b.shape) == (2, 8, 4, 6, 1) and b.dtype == torch.float32 for b in got)
+    assert torch.equal(got[1][1, :, :, :, 0], torch.from_numpy(v[3].astype(np.float32)))
+    assert torch.equal(got[0], got[2])
+    rgba = rng.random((2, 8, 4, 6, 4))
+    b = next(ds.batches(rgba, 2, 8, 4, 6, 3))
+    assert tuple(b.shape) == (2, 8, 4, 6, 3) and torch.equal(b, torch.from_numpy(rgba[..., :3].astype(np.float32)))
+    sq = ds.synthetic_moving_squares(3, 16, 5, 16, seed=1)
+    assert sq.shape == (5, 3, 16, 16) and sq.dtype == np.uint8 and set(np.unique(sq)) == {0, 255}
+    assert all(int((sq[t, i] == 255).sum()) == 36 for t in range(5) for i in range(3))
+    import pytest
+    with pytest.raises(ValueError):
+        ds.mmnist_videos(mm, 8)
