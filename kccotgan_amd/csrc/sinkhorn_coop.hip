@@ -319,6 +319,335 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_coop(SinkCoopBwdArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Flag-in-data exchange ("LL" kernels, the default).
+//
+// The counter barrier above costs ~3.9 us per half-step at n = 256: a workgroup barrier that drains the store
+// queue, an L2 write-back (release), an atomic round trip, polling, an invalidate (acquire) and only then the loads
+// of the new duals.  Here every dual travels as ONE 64-bit word {value, tag}: the tag is the half-step number, the
+// store and the load are relaxed agent-scope atomics (a naturally aligned 64-bit access is single-copy atomic), so
+// a reader that sees the tag it waits for has the value -- no fences, no counter, no separate flag.  Wave 0 of every
+// workgroup polls the n words of the side it needs, puts the values in LDS, and one LDS-only workgroup barrier
+// releases the other fifteen waves.  A word is overwritten (tag + 2) only by a workgroup that has gathered the whole
+// other side with tag + 1, and those words are published only by workgroups that have gathered this side with
+// `tag`: nobody can lose a value.  The exchange words are zeroed in front of every launch (tags start at 1).
+// Polling is bounded and honours the abort flag exactly as grid_barrier does.
+// The stop test needs sum_i |u_i - u_i_prev| (gan_utils.py:157): every wave holds all of u (new and previous) across
+// its lanes after the gather, so each wave sums it for itself in the same fixed order -- identical decisions, no
+// exchange.
+typedef unsigned long long ll_word;
+constexpr unsigned LL_FINAL_TAG = 0x7FFFFFFFu;
+
+__device__ __forceinline__ void ll_store(ll_word* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((ll_word)tag << 32) | (ll_word)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Gather of x[0..n) with tag `tag` into sh[0..n): wave c < ceil(n/256) polls words 256c .. 256c+255 (four per lane).
+// false = gave up (abort raised).
+__device__ __forceinline__ bool ll_gather(const ll_word* x, unsigned tag, float* sh, int lane, int chunk, int n, int* abort_flag) {
+    unsigned spins = 0;
+    const int base = chunk * 256 + lane;
+    for (;;) {
+        ll_word w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = base + 64 * e;
+            w[e] = __hip_atomic_load(x + (idx < n ? idx : n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ok = ok && ((unsigned)(w[e] >> 32) == tag);
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = base + 64 * e;
+                if (idx < n) sh[idx] = __uint_as_float((unsigned)w[e]);
+            }
+            return true;
+        }
+        if ((++spins & 127u) == 0) {
+            if (spins > SC_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+struct SinkLLArgs {
+    const float* C;
+    int n, L, Lmin, stop_mode;
+    float eps, inv_eps, thresh;
+    float* u_hist;
+    float* v_hist;
+    float* cost_out;
+    int32_t* nits_out;
+    float* pi_out;
+    CoopCtrl* ctrl;
+    ll_word* xu;      // [nprob][n]
+    ll_word* xv;      // [nprob][n]
+    ll_word* xcost;   // [nprob][SC_MAXWG]
+    int nwg, nprob, xcd_map;
+};
+
+// blockIdx -> (problem, workgroup of the problem).  xcd_map: workgroups are dealt round-robin to the 8 XCDs, so
+// problem = id % 8 puts all workgroups of a problem behind ONE L2 (ids with id % 8 >= nprob have nothing to do).
+__device__ __forceinline__ bool ll_role(int xcd_map, int nwg, int nprob, int& p, int& wg) {
+    if (xcd_map) { p = blockIdx.x & 7; wg = blockIdx.x >> 3; return p < nprob && wg < nwg; }
+    p = blockIdx.y; wg = blockIdx.x;
+    return true;
+}
+
+template <int EPT>
+__global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
+    __shared__ float shu[SC_MAXWG * SC_LINES];
+    __shared__ float shv[SC_MAXWG * SC_LINES];
+    __shared__ float red[SC_MAXWG];
+    __shared__ int bflag;
+    int p, wg;
+    if (!ll_role(a.xcd_map, a.nwg, a.nprob, p, wg)) return;
+    const int n = a.n, nwg = a.nwg;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int line = wg * SC_LINES + w;
+    const bool live = line < n;
+    const int lsafe = live ? line : n - 1;
+    const float* C = a.C + (int64_t)p * n * n;
+    ll_word* xu = a.xu + (int64_t)p * n;
+    ll_word* xv = a.xv + (int64_t)p * n;
+    const float eps = a.eps, inv_eps = a.inv_eps;
+    const float log_w = logf(1.0f / (float)n);
+    const int nchunk = (n + 255) >> 8;                             // gathering waves
+    auto clampi = [&](int e) { const int idx = lane + 64 * e; return idx < n ? idx : n - 1; };   // masked in coop_update
+
+    float crow[EPT], ccol[EPT], ov[EPT], ou[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        crow[e] = C[(int64_t)lsafe * n + clampi(e)];
+        ccol[e] = C[(int64_t)clampi(e) * n + lsafe];
+        ov[e] = 0.f; ou[e] = 0.f;                                  // gan_utils.py:147: u = v = 0
+    }
+    if (t == 0) bflag = 0;
+    __syncthreads();
+    float ui = 0.f, vj = 0.f;
+    int nits = 0;
+    bool ok = true;
+    for (int it = 0; it < a.L; ++it) {
+        const unsigned tagu = 2u * it + 1u, tagv = 2u * it + 2u;
+        const float un = coop_update<EPT, true>(crow, ov, n, lane, ui, eps, inv_eps, log_w);
+        ui = un;
+        if (lane == 0 && live) {
+            ll_store(xu + line, un, tagu);
+            if (a.u_hist) a.u_hist[((int64_t)p * a.L + it) * n + line] = un;
+        }
+        if (w < nchunk && !ll_gather(xu, tagu, shu, lane, w, n, &a.ctrl->abort_flag) && lane == 0) bflag = 1;
+        lds_barrier();
+        if (*(volatile int*)&bflag) { ok = false; break; }
+        float errl = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const float nu = shu[clampi(e)];
+            errl += (lane + 64 * e < n) ? fabsf(nu - ou[e]) : 0.f;
+            ou[e] = nu;
+        }
+        const float vn = coop_update<EPT, false>(ccol, ou, n, lane, vj, eps, inv_eps, log_w);
+        vj = vn;
+        if (lane == 0 && live) {
+            ll_store(xv + line, vn, tagv);
+            if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + line] = vn;
+        }
+        if (w < nchunk && !ll_gather(xv, tagv, shv, lane, w, n, &a.ctrl->abort_flag) && lane == 0) bflag = 1;
+        lds_barrier();
+        if (*(volatile int*)&bflag) { ok = false; break; }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) ov[e] = shv[clampi(e)];
+        nits = it + 1;
+        // gan_utils.py:157-160 (count-based) / :115-117 (index-based); every wave sums the same values in the same order
+        const bool reached = (a.stop_mode == KCCOT_STOP_INDEX) ? (it >= a.Lmin) : (nits >= a.Lmin);
+        if (reached && it + 1 < a.L) {
+            const float err = wave_sum_fast(errl);
+            if (a.thresh > err) break;
+        }
+    }
+    // gan_utils.py:162-164: pi = exp((-C + u + v^T)/eps); cost = sum(pi * C)
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = lane + 64 * e;
+        if (ok && live && idx < n) {
+            const float pi = __builtin_amdgcn_exp2f(((-crow[e] + ui) + ov[e]) * inv_eps * SC_LOG2E);
+            part += pi * crow[e];
+            if (a.pi_out) a.pi_out[(int64_t)p * n * n + (int64_t)line * n + idx] = pi;
+        }
+    }
+    part = wave_sum_fast(part);
+    __syncthreads();
+    if (lane == 0) red[w] = part;
+    __syncthreads();
+    if (t == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < SC_LINES; ++k) s += red[k];
+        if (ok) ll_store(a.xcost + p * SC_MAXWG + wg, s, LL_FINAL_TAG);   // a workgroup that gave up never publishes
+    }
+    if (wg != 0 || w != 0) return;
+    // workgroup 0, wave 0: the per-workgroup parts in workgroup order
+    {
+        const int k = lane < nwg ? lane : nwg - 1;
+        unsigned spins = 0;
+        bool got = false, dead = !ok;
+        float val = 0.f;
+        while (!dead) {
+            const ll_word wv = __hip_atomic_load(a.xcost + p * SC_MAXWG + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            got = (unsigned)(wv >> 32) == LL_FINAL_TAG;
+            val = __uint_as_float((unsigned)wv);
+            if (__builtin_amdgcn_ballot_w64(!got) == 0) break;
+            if ((++spins & 127u) == 0 &&
+                (spins > SC_SPIN_LIMIT || __hip_atomic_load(&a.ctrl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&a.ctrl->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (__hip_atomic_load(&a.ctrl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
+        float s = 0.f;
+        for (int q = 0; q < nwg; ++q) s += __shfl(val, q, 64);
+        if (lane == 0) {
+            a.cost_out[p] = dead ? NAN : s;      // an aborted solve must not look like a result
+            a.nits_out[p] = nits;
+            a.nits_out[a.nprob + p] = nits;
+        }
+    }
+}
+
+struct SinkLLBwdArgs {
+    const float* C;
+    const float* u_hist;
+    const float* v_hist;
+    const int32_t* nits;
+    const float* gcost;
+    float* dC;
+    float* dCT;
+    int n, L;
+    float eps, inv_eps;
+    CoopCtrl* ctrl;
+    ll_word* xgu;
+    ll_word* xgv;
+    int nwg, nprob, xcd_map;
+};
+
+template <int EPT>
+__global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
+    __shared__ float shu[SC_MAXWG * SC_LINES];
+    __shared__ float shv[SC_MAXWG * SC_LINES];
+    __shared__ int bflag;
+    int p, wg;
+    if (!ll_role(a.xcd_map, a.nwg, a.nprob, p, wg)) return;
+    const int n = a.n;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int line = wg * SC_LINES + w;
+    const bool live = line < n;
+    const int lsafe = live ? line : n - 1;
+    const float* C = a.C + (int64_t)p * n * n;
+    ll_word* xgu = a.xgu + (int64_t)p * n;
+    ll_word* xgv = a.xgv + (int64_t)p * n;
+    const float eps = a.eps, inv_eps = a.inv_eps, g = a.gcost[p];
+    const int nits = a.nits[p];
+    const float* uh = a.u_hist + (int64_t)p * a.L * n;     // history index k holds (u_{k+1}, v_{k+1}); u_0 = v_0 = 0
+    const float* vh = a.v_hist + (int64_t)p * a.L * n;
+    const float aconst = eps * logf(1.0f / (float)n);
+
+    const int nchunk = (n + 255) >> 8;                             // gathering waves
+    constexpr bool PREFETCH = EPT <= 8;                            // history loads issued ahead of the gathers (registers permitting)
+    auto clampi = [&](int e) { const int idx = lane + 64 * e; return idx < n ? idx : n - 1; };
+    auto okc = [&](int e) { return live && lane + 64 * e < n; };
+    float crow[EPT], ccol[EPT], drow[EPT], dcol[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        crow[e] = C[(int64_t)lsafe * n + clampi(e)];
+        ccol[e] = C[(int64_t)clampi(e) * n + lsafe];
+        drow[e] = 0.f; dcol[e] = 0.f;
+    }
+    if (t == 0) bflag = 0;
+    __syncthreads();
+    auto hist = [&](const float* h, int it, int i) { return it >= 1 ? h[(int64_t)(it - 1) * n + i] : 0.f; };
+    // final-cost term: dC = g pi (1 - C/eps); gu = g sum_j pi C / eps; gv likewise
+    float gu_line, gv_line;
+    {
+        const float ui = hist(uh, nits, lsafe), vj = hist(vh, nits, lsafe);
+        float su = 0.f, sv = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const float vo = hist(vh, nits, clampi(e)), uo = hist(uh, nits, clampi(e));
+            const float pr = okc(e) ? __builtin_amdgcn_exp2f(((-crow[e] + ui) + vo) * inv_eps * SC_LOG2E) : 0.f;
+            drow[e] = g * pr * (1.f - crow[e] * inv_eps);
+            su += pr * crow[e];
+            const float pc = okc(e) ? __builtin_amdgcn_exp2f(((-ccol[e] + uo) + vj) * inv_eps * SC_LOG2E) : 0.f;
+            sv += pc * ccol[e];
+        }
+        gu_line = g * wave_sum_fast(su) * inv_eps;
+        gv_line = g * wave_sum_fast(sv) * inv_eps;
+        if (lane == 0 && live) ll_store(xgv + line, gv_line, 1u);
+    }
+    unsigned tag = 1u;       // the tag of the gv values the next (A) pass reads
+    for (int it = nits; it >= 1; --it) {
+        // prefetch this iteration's history (plain loads: written by the forward kernel)
+        float vo[PREFETCH ? EPT : 1], uo[PREFETCH ? EPT : 1];
+        const float ui = hist(uh, it, lsafe), vj = hist(vh, it - 1, lsafe);
+        if (PREFETCH) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) { vo[e] = hist(vh, it, clampi(e)); uo[e] = hist(uh, it, clampi(e)); }
+        }
+        // (A) row pass with Q_t: gu_i = [it == nits] gu_i - sum_j Q_ij gv_j ; dC_ij += Q_ij gv_j
+        if (w < nchunk && !ll_gather(xgv, tag, shv, lane, w, n, &a.ctrl->abort_flag) && lane == 0) bflag = 1;
+        lds_barrier();
+        if (*(volatile int*)&bflag) break;
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const float gvj = shv[clampi(e)];
+                const float qq = okc(e) ? __builtin_amdgcn_exp2f((((-crow[e] + ui) + (PREFETCH ? vo[PREFETCH ? e : 0] : hist(vh, it, clampi(e)))) - aconst) * inv_eps * SC_LOG2E) : 0.f;
+                const float wv = qq * gvj;
+                drow[e] += wv;
+                s += wv;
+            }
+            s = wave_sum_fast(s);
+            gu_line = (it == nits ? gu_line : 0.f) - s;
+            if (lane == 0 && live) ll_store(xgu + line, gu_line, tag + 1u);
+        }
+        // (B) column pass with P_t: gv_j = -sum_i P_ij gu_i ; dC_ij += P_ij gu_i (kept in column layout)
+        if (w < nchunk && !ll_gather(xgu, tag + 1u, shu, lane, w, n, &a.ctrl->abort_flag) && lane == 0) bflag = 1;
+        lds_barrier();
+        if (*(volatile int*)&bflag) break;
+        {
+            float r = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const float gui = shu[clampi(e)];
+                const float pp = okc(e) ? __builtin_amdgcn_exp2f((((-ccol[e] + (PREFETCH ? uo[PREFETCH ? e : 0] : hist(uh, it, clampi(e)))) + vj) - aconst) * inv_eps * SC_LOG2E) : 0.f;
+                const float wv = pp * gui;
+                dcol[e] += wv;
+                r += wv;
+            }
+            r = wave_sum_fast(r);
+            gv_line = -r;
+            if (lane == 0 && live) ll_store(xgv + line, gv_line, tag + 2u);
+        }
+        tag += 2u;
+    }
+    const bool bad = *(volatile int*)&bflag != 0;
+    float* dC = a.dC + (int64_t)p * n * n;
+    float* dCT = a.dCT + (int64_t)p * n * n;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        if (okc(e)) {
+            dC[(int64_t)line * n + clampi(e)] = bad ? NAN : drow[e];
+            dCT[(int64_t)line * n + clampi(e)] = bad ? NAN : dcol[e];      // row `line` of dC^T = column `line` of dC
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------
 size_t sinkhorn_gen_workspace_bytes(int nprob, int n);
 __global__ void add_transposed_batched(const float* __restrict__ in, float* __restrict__ out, int n);
@@ -345,9 +674,50 @@ static CoopCarve coop_carve(void* ws, int nprob, int n) {
     return c;
 }
 
+// flag-in-data kernels: ctrl | xu [nprob][n] words | xv | xcost [nprob][SC_MAXWG] words, zeroed as one block
+struct LLCarve { CoopCtrl* ctrl; ll_word* x0; ll_word* x1; ll_word* xc; size_t zero_bytes; float* second; };
+static LLCarve ll_carve(void* ws, int nprob, int n) {
+    char* b = static_cast<char*>(ws);
+    LLCarve c;
+    c.ctrl = reinterpret_cast<CoopCtrl*>(b);
+    c.x0 = reinterpret_cast<ll_word*>(b + sizeof(CoopCtrl));
+    c.x1 = c.x0 + (size_t)nprob * n;
+    c.xc = c.x1 + (size_t)nprob * n;
+    c.zero_bytes = sizeof(CoopCtrl) + ((size_t)2 * nprob * n + (size_t)nprob * SC_MAXWG) * sizeof(ll_word);
+    c.second = reinterpret_cast<float*>(b + sinkhorn_gen_workspace_bytes(nprob, n) / 2);
+    return c;
+}
+static bool ll_enabled() {
+    const char* e = getenv("KCCOT_SK_COOP_BARRIER");   // =1: the counter-barrier kernels (A/B)
+    return !(e && atoi(e) == 1);
+}
+// KCCOT_SK_COOP_XCD=1: all workgroups of a problem on one XCD (needs nprob <= 8 and at most one workgroup per CU of
+// an XCD).  Measured SLOWER than the plain grid (n = 256: 5.6 vs 4.5 us per iteration, n = 512: 9.3 vs 5.5) -- the
+// agent-scope words are served by the fabric either way, and one XCD's share of it is the narrower path -- so it is
+// off by default and kept as an experiment knob.
+static bool ll_xcd_map(int nprob, int nwg) {
+    const char* e = getenv("KCCOT_SK_COOP_XCD");
+    return e && atoi(e) == 1 && nprob <= 8 && nwg <= 32;
+}
+
 int launch_sinkhorn_fwd_coop(const float* C, int nprob, int n, float eps, int L, int Lmin, float thresh, int stop_mode,
                              float* u_hist, float* v_hist, float* cost_out, int32_t* nits_out, float* pi_out, void* ws,
                              hipStream_t st) {
+    if (ll_enabled()) {
+        const LLCarve lv = ll_carve(ws, nprob, n);
+        if (lv.zero_bytes > sinkhorn_gen_workspace_bytes(nprob, n) / 2) return fail(KCCOT_EWORKSPACE, "sinkhorn_fwd(coop): exchange area");
+        if (hipMemsetAsync(lv.ctrl, 0, lv.zero_bytes, st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_fwd(coop): memset failed");
+        const int nwg = (n + SC_LINES - 1) / SC_LINES;
+        const int xm = ll_xcd_map(nprob, nwg) ? 1 : 0;
+        SinkLLArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
+                     lv.ctrl, lv.x0, lv.x1, lv.xc, nwg, nprob, xm};
+        const dim3 grid = xm ? dim3(8 * nwg) : dim3(nwg, nprob);
+        const int ept = (n + 63) / 64;
+#define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_fwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)
+        if (ept <= 4) KCCOT_LL(4); else if (ept <= 8) KCCOT_LL(8); else KCCOT_LL(16);
+#undef KCCOT_LL
+        return launch_status("sinkhorn_fwd_ll");
+    }
     const CoopCarve cv = coop_carve(ws, nprob, n);
     if (hipMemsetAsync(cv.ctrl, 0, sizeof(CoopCtrl), st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_fwd(coop): memset failed");
     SinkCoopArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
@@ -362,6 +732,25 @@ int launch_sinkhorn_fwd_coop(const float* C, int nprob, int n, float eps, int L,
 
 int launch_sinkhorn_bwd_coop(const float* C, const float* u_hist, const float* v_hist, const int32_t* nits, int nprob, int n,
                              float eps, int L, const float* gcost, float* dC, void* ws, hipStream_t st) {
+    if (ll_enabled()) {
+        const LLCarve lv = ll_carve(ws, nprob, n);
+        if (lv.zero_bytes > sinkhorn_gen_workspace_bytes(nprob, n) / 2) return fail(KCCOT_EWORKSPACE, "sinkhorn_bwd(coop): exchange area");
+        if (hipMemsetAsync(lv.ctrl, 0, lv.zero_bytes, st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_bwd(coop): memset failed");
+        const int nwg = (n + SC_LINES - 1) / SC_LINES;
+        const int xm = ll_xcd_map(nprob, nwg) ? 1 : 0;
+        SinkLLBwdArgs a{C, u_hist, v_hist, nits, gcost, dC, lv.second, n, L, eps, (float)(1.0 / (double)eps), lv.ctrl, lv.x0, lv.x1,
+                        nwg, nprob, xm};
+        const dim3 grid = xm ? dim3(8 * nwg) : dim3(nwg, nprob);
+        const int ept = (n + 63) / 64;
+#define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_bwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)
+        if (ept <= 4) KCCOT_LL(4); else if (ept <= 8) KCCOT_LL(8); else KCCOT_LL(16);
+#undef KCCOT_LL
+        int rc = launch_status("sinkhorn_bwd_ll");
+        if (rc) return rc;
+        dim3 tg((n + 31) / 32, (n + 31) / 32, nprob);
+        hipLaunchKernelGGL(add_transposed_batched, tg, dim3(256), 0, st, (const float*)lv.second, dC, n);
+        return launch_status("add_transposed_batched");
+    }
     const CoopCarve cv = coop_carve(ws, nprob, n);
     if (hipMemsetAsync(cv.ctrl, 0, sizeof(CoopCtrl), st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_bwd(coop): memset failed");
     SinkCoopBwdArgs a{C, u_hist, v_hist, nits, gcost, dC, cv.second, n, L, eps, (float)(1.0 / (double)eps), cv.ctrl, cv.x0, cv.x1};

@@ -273,15 +273,25 @@ def test_sinkhorn_periodic_state_shortcut_is_bit_exact(G, L):
     assert skipped_somewhere      # the test must exercise the jump, not only the fall-through
 
 
-@pytest.mark.parametrize("solver", ["coop", "stream"])
+_SOLVER_ENV = {"coop": {}, "coop_barrier": {"KCCOT_SK_COOP_BARRIER": "1"}, "coop_xcd": {"KCCOT_SK_COOP_XCD": "1"},
+               "stream": {"KCCOT_SK_NO_COOP": "1"}}
+
+
+def _solver_env(solver):
+    for k in ("KCCOT_SK_COOP_BARRIER", "KCCOT_SK_COOP_XCD", "KCCOT_SK_NO_COOP"):
+        os.environ.pop(k, None)
+    os.environ.update(_SOLVER_ENV[solver])
+
+
+@pytest.mark.parametrize("solver", ["coop", "coop_barrier", "coop_xcd", "stream"])
 def test_sinkhorn_large_n_streaming_path(G, L, solver):
-    """n > 128 (BASELINE configs 3-5 batch sizes): the multi-CU cooperative solver (default) and the
-    single-workgroup streaming kernels it falls back to (KCCOT_SK_NO_COOP=1), forward and reverse sweep,
-    against the oracle / fp64 autograd on random cost matrices."""
-    if solver == "stream":
-        os.environ["KCCOT_SK_NO_COOP"] = "1"
+    """n > 128 (BASELINE configs 3-5 batch sizes): the multi-CU cooperative solver (default: flag-in-data exchange;
+    KCCOT_SK_COOP_BARRIER=1: counter barrier; KCCOT_SK_COOP_XCD=1: one XCD per problem) and the single-workgroup
+    streaming kernels it falls back to (KCCOT_SK_NO_COOP=1), forward and reverse sweep, against the oracle / fp64
+    autograd on random cost matrices."""
+    _solver_env(solver)
     try:
-        for n, Lc, eps in ((130, 25, 0.7), (256, 40, 1.0), (512, 12, 0.5)):
+        for n, Lc, eps in ((130, 25, 0.7), (256, 40, 1.0), (512, 12, 0.5), (1000, 5, 1.0)):
             Cn = (np.random.default_rng(n).random((2, n, n), dtype=np.float32) * 6).astype(np.float32)
             C = torch.from_numpy(Cn).to(DEV).requires_grad_(True)
             cost = G._Sinkhorn.apply(C, eps, Lc, 100, L.STOP_COUNT, "large")
@@ -296,7 +306,7 @@ def test_sinkhorn_large_n_streaming_path(G, L, solver):
                 gref = Cd.grad.numpy() * float(w[p])
                 np.testing.assert_allclose(C.grad[p].cpu().numpy(), gref, rtol=0, atol=2e-4 * np.abs(gref).max())
     finally:
-        os.environ.pop("KCCOT_SK_NO_COOP", None)
+        _solver_env("coop")
 
 
 def test_sinkhorn_cooperative_stop_rule_and_many_problems(G, L):
@@ -308,16 +318,16 @@ def test_sinkhorn_cooperative_stop_rule_and_many_problems(G, L):
     Cn = (rng.random((3, n, n), dtype=np.float32) * 3).astype(np.float32)
     C = torch.from_numpy(Cn).to(DEV)
     res = {}
-    for solver in ("coop", "stream"):
-        if solver == "stream":
-            os.environ["KCCOT_SK_NO_COOP"] = "1"
+    for solver in ("coop", "coop_barrier", "stream"):
+        _solver_env(solver)
         try:
             cost = G._Sinkhorn.apply(C, 1.0, 400, 100, L.STOP_COUNT, "stop")
             res[solver] = (cost.cpu().numpy(), G.last_info["stop"].tolist())
         finally:
-            os.environ.pop("KCCOT_SK_NO_COOP", None)
-    assert res["coop"][1] == res["stream"][1] and res["coop"][1][0] < 400
+            _solver_env("coop")
+    assert res["coop"][1] == res["stream"][1] == res["coop_barrier"][1] and res["coop"][1][0] < 400
     np.testing.assert_allclose(res["coop"][0], res["stream"][0], rtol=2e-5)
+    assert np.array_equal(res["coop"][0], res["coop_barrier"][0])      # same arithmetic, only the exchange differs
     many = torch.from_numpy((rng.random((24, n, n), dtype=np.float32) * 3).astype(np.float32)).to(DEV)   # 24 x 10 workgroups > 192
     cost = G._Sinkhorn.apply(many, 1.0, 30, 100, L.STOP_COUNT, "many")
     ref = [o.sinkhorn_from_cost(many[p].cpu().numpy(), 1.0, 30)[0] for p in (0, 23)]
