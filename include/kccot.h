@@ -208,6 +208,11 @@ int kccot_martingale_bwd_f32(const float* M, int B, int T, int J, float lam, flo
  * ------------------------------------------------------------------------------------------- */
 int kccot_rbf_mmd_f32(const float* D3, int B, float gamma, float* K3_out, float* mmd_out,
                       kccot_stream_t stream);
+/* Backward of the estimate w.r.t. the distances: gD3 [3,B,B] = gmmd * d mmd / d D3 from the kernel
+ * matrices K3 of the forward; gmmd is ONE device float.  Feed gD3 to kccot_pairwise_cost3_bwd_f32
+ * (sc = 1, no features) for the gradient w.r.t. `fake`. */
+int kccot_rbf_mmd_bwd_f32(const float* K3, int B, float gamma, const float* gmmd, float* gD3,
+                          kccot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel smoothing.  Replaces KernelSmoothing.temporal_convolution (data_utils.py:503-521,

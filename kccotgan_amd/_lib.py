@@ -55,6 +55,7 @@ SIGNATURES = {
     "kccot_martingale_fwd_f32": (_i, [_fp, _i, _i, _i, _f, _f, _fp, _fp]),
     "kccot_martingale_bwd_f32": (_i, [_fp, _i, _i, _i, _f, _f, _fp, _fp, _fp]),
     "kccot_rbf_mmd_f32": (_i, [_fp, _i, _f, _fp, _fp, _fp]),
+    "kccot_rbf_mmd_bwd_f32": (_i, [_fp, _i, _f, _fp, _fp, _fp]),
     "kccot_smooth_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "kccot_smooth_fwd_f32": (_i, [_fp, _i, _i, _i, _i, _i, _f, _i, _u, _fp, _fp, _fp, _sz, _fp]),
     "kccot_smooth_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _i, _u, _fp, _fp, _sz, _fp]),

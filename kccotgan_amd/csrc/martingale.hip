@@ -106,9 +106,28 @@ __global__ __launch_bounds__(1024) void rbf_mmd(const float* __restrict__ D3, in
     }
 }
 
+// d mmd / d D3: mmd = (sum Kxx + sum Kyy - 2 sum Kxy) / B^2 with K = exp(-gamma D), so
+// gD3[p] = gmmd * coef_p * (-gamma) * K3[p] / B^2, coef = (-2, +1, +1) for (xy, xx, yy).
+__global__ __launch_bounds__(256) void rbf_mmd_bwd(const float* __restrict__ K3, int B, float gamma,
+                                                   const float* __restrict__ gmmd, float* __restrict__ gD3) {
+    const int64_t n = (int64_t)B * B, e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 3 * n) return;
+    const float coef = e < n ? -2.f : 1.f;
+    gD3[e] = gmmd[0] * coef * (-gamma) * K3[e] / (float)n;
+}
+
 }  // namespace kccot
 
 using namespace kccot;
+
+extern "C" int kccot_rbf_mmd_bwd_f32(const float* K3, int B, float gamma, const float* gmmd, float* gD3,
+                                     kccot_stream_t stream) {
+    if (!K3 || !gmmd || !gD3) return fail(KCCOT_EINVAL, "rbf_mmd_bwd: null pointer");
+    if (B <= 0 || !(gamma > 0.f)) return fail(KCCOT_EINVAL, "rbf_mmd_bwd: bad arguments B=%d gamma=%g", B, (double)gamma);
+    const int64_t n3 = (int64_t)3 * B * B;
+    hipLaunchKernelGGL(rbf_mmd_bwd, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K3, B, gamma, gmmd, gD3);
+    return launch_status("rbf_mmd_bwd");
+}
 
 extern "C" int kccot_rbf_mmd_f32(const float* D3, int B, float gamma, float* K3_out, float* mmd_out,
                                  kccot_stream_t stream) {

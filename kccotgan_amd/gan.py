@@ -25,17 +25,34 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-# Layer families listed in KCCOT_NATIVE_CONV (comma separated: convlstm, deconv, dconv) run on the native
-# ATen convolution kernels instead of MIOpen's.  Default: all three -- with MIOpen's convolutions the
-# backward of the generator overruns a buffer on this ROCm image (a pure-PyTorch loop faults as soon as the
-# allocator layout exposes it).  KCCOT_NATIVE_CONV= (empty) selects MIOpen: 9x faster
-# per training iteration when it does not fault.
-_NATIVE_DEFAULT = "convlstm,deconv,dconv"
+# MIOpen's `ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC` solver (kernel `igemm_bwd_gtcx35_nhwc_fp32_*`) reads past the
+# end of a buffer in the backward of these models on this ROCm image: "Memory access fault by GPU" on a 2 MB segment
+# boundary whenever the caching allocator happens to place the overrun buffer at the end of a segment (found with
+# AMD_LOG_LEVEL=3 + blocking launches; a pure-PyTorch loop reproduces it).  With that one solver
+# switched off MIOpen picks another backward-data kernel and every run has been clean, at 0.93 s per full-size
+# training iteration (0.76 s with the faulting solver, 6.6 s on the native ATen kernels).  The switch is an
+# environment variable MIOpen reads when it selects solvers, so it is set here, at import, unless the user set it.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
+
+# Layer families listed in KCCOT_NATIVE_CONV (comma separated: convlstm, deconv, dconv) run on the native ATen
+# convolution kernels instead of MIOpen's (the conservative mode: no MIOpen kernel at all when all three are listed;
+# the forward contexts below cover the forward calls, `conv_guard` the backward).  Default: none.
+_NATIVE_DEFAULT = ""
 _NATIVE = set(filter(None, os.environ.get("KCCOT_NATIVE_CONV", _NATIVE_DEFAULT).split(",")))
 
 
 def _backend(kind):
     return torch.backends.cudnn.flags(enabled=False) if kind in _NATIVE else contextlib.nullcontext()
+
+
+def conv_guard():
+    """Context for everything that runs these models' BACKWARD (``loss.backward()`` / ``torch.autograd.grad``).
+    The per-family contexts above only cover the forward calls: ``convolution_backward`` picks its backend again,
+    from the process-wide flag, when the autograd engine runs it -- outside any forward-time context.  (Found with
+    AMD_LOG_LEVEL=3 + blocking launches: the faulting kernel of a 'native' run was MIOpen's
+    ``igemm_bwd_gtcx35_nhwc_fp32`` in the generator's backward.)  With any family listed in KCCOT_NATIVE_CONV the
+    guard switches MIOpen off for the whole region; KernelTrainer wraps both training steps and ``sample`` in it."""
+    return torch.backends.cudnn.flags(enabled=False) if _NATIVE else contextlib.nullcontext()
 
 
 def _same_pad(size, k, s):

@@ -124,6 +124,14 @@ class KCCOTTrainer:
 
     # ------------------------------------------------------------------ kernel_train.py:219-256
     def disc_training_step(self, real_in, real_pred, sigma):
+        with gan.conv_guard():                   # forward AND backward off MIOpen when native convolutions are selected
+            return self._disc_training_step(real_in, real_pred, sigma)
+
+    def gen_training_step(self, real_in, real_pred, sigma):
+        with gan.conv_guard():
+            return self._gen_training_step(real_in, real_pred, sigma)
+
+    def _disc_training_step(self, real_in, real_pred, sigma):
         self.dischm_optimiser.zero_grad(set_to_none=True)
         loss, m_real = self._forward(real_in, real_pred, sigma, generator_grad=False)
         if self._world() > 1:               # pM couples the whole batch (std and mean over b): use the global M
@@ -139,7 +147,7 @@ class KCCOTTrainer:
         return pm1.detach()                                                      # :256
 
     # ------------------------------------------------------------------ kernel_train.py:259-292
-    def gen_training_step(self, real_in, real_pred, sigma):
+    def _gen_training_step(self, real_in, real_pred, sigma):
         self.gen_optimiser.zero_grad(set_to_none=True)
         loss, _ = self._forward(real_in, real_pred, sigma)
         grads = torch.autograd.grad(loss, self.g_params, allow_unused=True)      # :289
@@ -158,11 +166,12 @@ class KCCOTTrainer:
         reads only the last encoded frame, gan.py:269-272) and append the frame.  Returns [B,H,T_total,W,C]."""
         test_inputs = test_data[:, :, :self.int_time_steps].to(self.device, torch.float32)
         z_shape = (self.batch_size, 1) + tuple(self.z_shape[2:])
-        for _ in range(self.pred_time_steps):
-            preds_features = self.context_encoder(test_inputs, training=False)
-            hidden_z = torch.randn(z_shape, device=self.device)
-            preds = self.decoder(preds_features, hidden_z, training=False)
-            test_inputs = torch.cat((test_inputs, preds), dim=2)
+        with gan.conv_guard():
+            for _ in range(self.pred_time_steps):
+                preds_features = self.context_encoder(test_inputs, training=False)
+                hidden_z = torch.randn(z_shape, device=self.device)
+                preds = self.decoder(preds_features, hidden_z, training=False)
+                test_inputs = torch.cat((test_inputs, preds), dim=2)
         return test_inputs
 
     @staticmethod

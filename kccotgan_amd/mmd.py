@@ -5,7 +5,9 @@ reference points at is sklearn's, so that is the spec here: ``K(x, y) = exp(-gam
 ``gamma`` defaulting to ``1 / n_features``; pinned against sklearn in tests (a pin of THIS build's
 spec, not of the reference).  The squared distances come from the same one-pass cost kernel as the
 loss (stacked Gram on the MFMA pipe), so the kernel matrices cost one exp per entry on top.
-Forward only.
+``rbf_mmd2`` is differentiable w.r.t. ``fake`` (the generator side, as everywhere on the loss path:
+kernel_train.py:252,289 never differentiate w.r.t. real): d mmd / d D3 is one elementwise kernel, the
+video gradient reuses the loss path's ``kccot_pairwise_cost3_bwd_f32``.
 """
 import torch
 
@@ -37,6 +39,36 @@ def rbf_kernels(real, fake, gamma=None):
     return K3, mmd.reshape(())
 
 
+class _RbfMMD2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, real, fake, gamma):
+        shape = fake.shape
+        B = real.shape[0]
+        real2 = real.reshape(B, -1).float().contiguous()
+        fake2 = fake.reshape(B, -1).float().contiguous()
+        K3, m = rbf_kernels(real2, fake2, gamma)
+        ctx.save_for_backward(real2, fake2, K3)
+        ctx.cfg = (float(gamma) if gamma is not None else 1.0 / real2.shape[1], shape)
+        return m
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("rbf_mmd2 differentiates w.r.t. fake only (the loss path never needs d/d real)")
+        real, fake, K3 = ctx.saved_tensors
+        gamma, shape = ctx.cfg
+        B, K = real.shape
+        g = g.reshape(1).float().contiguous()
+        gD3 = _lib.empty_like(K3)
+        check(lib.kccot_rbf_mmd_bwd_f32(ptr(K3), B, gamma, ptr(g), ptr(gD3), stream_of(K3)), "rbf_mmd_bwd")
+        dfake = _lib.empty_like(fake)
+        ws, wsb = workspace(lib.kccot_pairwise_cost3_bwd_workspace_bytes(B, K), real)
+        check(lib.kccot_pairwise_cost3_bwd_f32(ptr(gD3), ptr(real), ptr(fake), B, K, 1.0, None, None, None, None, 1, 1,
+                                               ptr(dfake), None, None, None, None, ws, wsb, stream_of(real)),
+              "pairwise_cost3_bwd")
+        return None, dfake.reshape(shape), None
+
+
 def rbf_mmd2(real, fake, gamma=None):
-    """mean(K(real,real)) + mean(K(fake,fake)) - 2 mean(K(real,fake))."""
-    return rbf_kernels(real, fake, gamma)[1]
+    """mean(K(real,real)) + mean(K(fake,fake)) - 2 mean(K(real,fake)); differentiable w.r.t. ``fake``."""
+    return _RbfMMD2.apply(real, fake, gamma)

@@ -632,6 +632,26 @@ def test_rbf_mmd_matches_sklearn_definition():
         assert abs(float(m2) - want2) < 1e-5 * max(abs(want2), 1e-3)
 
 
+def test_rbf_mmd_gradient_wrt_fake():
+    """d mmd^2 / d fake against fp64 autograd of the same definition (B = 16 small K; B = 128 through the blocked costs)."""
+    from kccotgan_amd import mmd
+    rng = np.random.default_rng(22)
+    for B, K, gamma in ((16, 320, None), (64, 2048, 0.002), (128, 512, 0.01)):
+        x = rng.random((B, K), dtype=np.float32)
+        y = np.clip(x + 0.2 * rng.standard_normal((B, K), dtype=np.float32), 0, 1).astype(np.float32)
+        yt = torch.from_numpy(y).to(DEV).requires_grad_(True)
+        m = mmd.rbf_mmd2(torch.from_numpy(x).to(DEV), yt, gamma)
+        (3.0 * m).backward()
+        xd, yd = torch.from_numpy(x).double(), torch.from_numpy(y).double().requires_grad_(True)
+        gm = gamma if gamma is not None else 1.0 / K
+        kern = lambda a, b: torch.exp(-gm * torch.cdist(a, b) ** 2)
+        ref = kern(xd, xd).mean() + kern(yd, yd).mean() - 2 * kern(xd, yd).mean()
+        (3.0 * ref).backward()
+        assert abs(float(m) - float(ref)) < 1e-5 * max(abs(float(ref)), 1e-3)
+        gref = yd.grad.numpy()
+        np.testing.assert_allclose(yt.grad.cpu().numpy(), gref, rtol=0, atol=2e-5 * np.abs(gref).max())
+
+
 # ---------------------------------------------------------------- one-call loss and graph capture
 def test_one_call_loss_equals_staged_path(G, L):
     """kccot_sinkhorn_loss_{fwd,bwd}_f32 only sequence the stage entry points: bit-identical to

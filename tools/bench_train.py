@@ -5,8 +5,8 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-if os.environ.get("KCCOT_TRAIN_MIOPEN") != "1":
-    torch.backends.cudnn.enabled = False      # see DESIGN.md section 7: MIOpen kernels of the generator backward fault
+if os.environ.get("KCCOT_TRAIN_NATIVE") == "1":
+    torch.backends.cudnn.enabled = False      # conservative mode: no MIOpen kernel at all
 from kccotgan_amd.kernel_train import KCCOTTrainer
 
 
