@@ -156,6 +156,17 @@ def main():
         from kccotgan_amd import dist as kd
         shard = kd.shard_batch(t, rank, world)
         step = lambda: kd.sharded_loss_step(shard, SC)
+        if os.environ.get("KCCOT_BENCH_EAGER") != "1":
+            # the collectives stay RCCL calls; the two compute segments between them replay as hipGraphs
+            # (kccotgan_amd/graph.py: the eager sharded step is host-bound, 0.36 ms of Python for 0.22 ms of kernels)
+            try:
+                from kccotgan_amd.graph import GraphedShardedStep
+                gstep = GraphedShardedStep(shard, SC)
+                step = lambda: gstep()
+                mode = "RCCL all-gathers + hipGraph replay of the two compute segments"
+            except Exception as e:
+                sys.stderr.write("bench: sharded graph capture failed (%r); timing eager launches\n" % (e,))
+                torch.cuda.synchronize()
     elif os.environ.get("KCCOT_BENCH_EAGER") == "1":
         step = lambda: loss_step(G, t)
     else:
@@ -191,7 +202,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt)
     ms = el / args.steps * 1e3
-    if world > 1:
+    if world > 1 and mode.startswith("RCCL"):
+        nits, nexec = gstep.nits.tolist(), gstep.nits_executed.tolist()
+    elif world > 1:
         from kccotgan_amd import dist as kd
         nits, nexec = kd.last_info["nits"].tolist(), kd.last_info["nits_executed"].tolist()
     elif mode == "eager launches":

@@ -19,6 +19,8 @@ The arithmetic is done by the HIP library (``HipOps``).  ``ops`` is injectable s
 sharding / collective logic can be exercised over gloo on a CPU-only box by the tests (which plug
 in the CPU oracle there); the product never does.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -60,6 +62,25 @@ class HipOps:
                                                 ptr(m_fake), T, J, row_begin, row_count, ptr(out), ws, wsb,
                                                 stream_of(real)), "pairwise_cost3_rows")
         return out
+
+    @staticmethod
+    def replicate_costs(B, K):
+        """Batches of at most 64: every rank assembles the WHOLE [3,B,B] with the one-pass MFMA kernels (31 us at
+        configs[1]) instead of its row block on the direct kernel (46-100 us) followed by another all-gather --
+        cheaper, one collective fewer, and the same pair-difference arithmetic as the single-GPU loss.  Larger batches
+        keep the row blocks (cost ~ B^2 K / G).  KCCOT_DIST_ROW_BLOCKS=1 forces the row-block protocol (tests, A/B).
+        The choice depends on (B, K) only, so all ranks agree."""
+        return B <= 64 and K % 4 == 0 and K >= 256 and os.environ.get("KCCOT_DIST_ROW_BLOCKS") != "1"
+
+    @staticmethod
+    def cost3_full(real, fake, h_fake, h_real, m_real, m_fake, sc):
+        B, K = real.shape
+        T, J = h_fake.shape[1], h_fake.shape[2]
+        C3 = _lib.empty((3, B, B), torch.float32, real.device)
+        ws, wsb = workspace(lib.kccot_pairwise_cost3_workspace_bytes(B, K), real)
+        check(lib.kccot_pairwise_cost3_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
+                                           ptr(m_fake), T, J, 0, ptr(C3), ws, wsb, stream_of(real)), "pairwise_cost3")
+        return C3
 
     @staticmethod
     def sinkhorn3_fwd(C3, eps, L):
@@ -182,14 +203,17 @@ class _ShardedLoss(torch.autograd.Function):
         # the four [Bl,T,J] feature shards travel as one message
         feats = all_gather_cat(torch.stack([h_fake_l, h_real_l, m_real_l, m_fake_l], dim=1), group)
         h_fake, h_real, m_real, m_fake = (feats[:, i].contiguous() for i in range(4))
-        # row blocks of the three cost matrices (gan_utils.py:221-223)
-        if hasattr(ops, "cost3_rows"):       # one launch for the three row blocks
-            blk = ops.cost3_rows(real, fake, h_fake, h_real, m_real, m_fake, sc, rank * Bl, Bl)
+        if hasattr(ops, "cost3_full") and ops.replicate_costs(real.shape[0], real.shape[1]):
+            C3 = ops.cost3_full(real, fake, h_fake, h_real, m_real, m_fake, sc)     # small batch: replicated assembly
         else:
-            blk = torch.stack([ops.cost_rows(real_l, fake, h_fake_l, m_real, sc),
-                               ops.cost_rows(real_l, real, h_real_l, m_real, sc),
-                               ops.cost_rows(fake_l, fake, h_fake_l, m_fake, sc)], dim=0)        # [3,Bl,B]
-        C3 = all_gather_cat(blk.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()  # [3,B,B]
+            # row blocks of the three cost matrices (gan_utils.py:221-223)
+            if hasattr(ops, "cost3_rows"):       # one launch for the three row blocks
+                blk = ops.cost3_rows(real, fake, h_fake, h_real, m_real, m_fake, sc, rank * Bl, Bl)
+            else:
+                blk = torch.stack([ops.cost_rows(real_l, fake, h_fake_l, m_real, sc),
+                                   ops.cost_rows(real_l, real, h_real_l, m_real, sc),
+                                   ops.cost_rows(fake_l, fake, h_fake_l, m_fake, sc)], dim=0)        # [3,Bl,B]
+            C3 = all_gather_cat(blk.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()  # [3,B,B]
         if hasattr(ops, "divergence_fwd"):       # solves + combination in one launch
             loss, saved = ops.divergence_fwd(C3, eps, L)
         else:

@@ -65,6 +65,16 @@ def run(rank, world, port, shape, seed, regime, device, use_hip, out_path):
     res = {"loss": np.array(float(loss))}
     for k, g in zip(names, grads):
         res["d" + k] = g.detach().cpu().double().numpy()
+    if use_hip:      # the graph-captured form of the same step (kccotgan_amd.graph.GraphedShardedStep): bit-identical
+        from kccotgan_amd.graph import GraphedShardedStep
+        step = GraphedShardedStep(shard, cases.SC, L=100)
+        for _ in range(2):
+            gl, gg = step()
+        res["graphed_loss_equal"] = np.array(bool(torch.equal(gl.reshape(()), loss.detach().reshape(()))))
+        res["graphed_grads_equal"] = np.array(all(bool(torch.equal(gg[k], g)) for k, g in zip(names, grads)))
+        # new local inputs through the call: the fake shard scaled by 0.5 must change the loss
+        gl2, _ = step(fake=shard["fake"].detach() * 0.5)
+        res["graphed_sees_new_inputs"] = np.array(not bool(torch.equal(gl2, loss.detach().reshape(()))))
     np.savez(out_path % rank, **res)
     dist.barrier()
     dist.destroy_process_group()

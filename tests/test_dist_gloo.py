@@ -28,11 +28,12 @@ def free_port():
     return p
 
 
-def launch(world, shape, seed, regime, device, mode, tmp_path):
+def launch(world, shape, seed, regime, device, mode, tmp_path, env=None):
     port = free_port()
     out = os.path.join(str(tmp_path), "rank%d.npz")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port),
-                               shape, str(seed), regime, device, mode, out]) for r in range(world)]
+                               shape, str(seed), regime, device, mode, out], env=dict(os.environ, **(env or {})))
+             for r in range(world)]
     try:
         for p in procs:
             assert p.wait(timeout=600) == 0
@@ -65,10 +66,15 @@ def test_sharded_equals_single_process_oracle(world, shape, seed, regime, tmp_pa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("protocol", ["replicated", "row_blocks"])
 @pytest.mark.parametrize("shape,seed,regime", [("deci64", 0, "near"), ("cfg1", 1, "far")])
-def test_sharded_hip_equals_single_gpu(shape, seed, regime, tmp_path):
+def test_sharded_hip_equals_single_gpu(shape, seed, regime, protocol, tmp_path):
+    """Two ranks (gloo, one GPU) against the single-GPU loss.  `replicated`: batches of at most 64 assemble the whole
+    cost matrices on every rank (HipOps.replicate_costs; cfg1's K = 24 576 qualifies, so does deci64);
+    `row_blocks`: the protocol of larger batches (row blocks on the direct kernel + all-gather), forced."""
     from kccotgan_amd import gan_utils as G
-    res = launch(2, shape, seed, regime, "cuda:0", "hip", tmp_path)
+    res = launch(2, shape, seed, regime, "cuda:0", "hip", tmp_path,
+                 env={"KCCOT_DIST_ROW_BLOCKS": "1"} if protocol == "row_blocks" else None)
     inp = cases.gen_inputs(shape, seed, regime)
     t = {k: torch.from_numpy(v).to("cuda:0") for k, v in inp.items()}
     for k in NAMES:
@@ -80,6 +86,10 @@ def test_sharded_hip_equals_single_gpu(shape, seed, regime, tmp_path):
     Bl = B // 2
     for r, out in enumerate(res):
         assert abs(float(out["loss"]) - float(ref)) <= 2e-6 * abs(float(ref))
+        if protocol == "replicated":       # the very kernels of the single-GPU loss: the same bits
+            assert float(out["loss"]) == float(ref)
+        # the graph-captured step (two graphs around the row-block all-gather) replays the eager step bit for bit
+        assert bool(out["graphed_loss_equal"]) and bool(out["graphed_grads_equal"]) and bool(out["graphed_sees_new_inputs"])
         for k, g in zip(NAMES, grads):
             g = g.cpu().double().numpy()
             want = g.reshape(B, -1)[r * Bl:(r + 1) * Bl]

@@ -32,5 +32,18 @@ for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
 shard = kd.shard_batch(t, 0, 1)
 loss, grads = kd.sharded_loss_step(shard, bench.SC)
 torch.cuda.synchronize()
+from kccotgan_amd.graph import GraphedShardedStep
+gs = GraphedShardedStep(shard, bench.SC)
+for _ in range(3):
+    gl, gg = gs()
+torch.cuda.synchronize()
+assert torch.equal(gl.reshape(()), loss.detach().reshape(())), (float(gl), float(loss))
+assert all(torch.equal(gg[k], g) for k, g in zip(("fake", "h_fake", "h_real", "m_real", "m_fake"), grads))
+import time
+t0 = time.perf_counter()
+for _ in range(100):
+    gs()
+torch.cuda.synchronize()
+print("graphed sharded step (world 1, nccl calls in place): %.1f us/step" % ((time.perf_counter() - t0) / 100 * 1e6))
 print("nccl selftest ok: backend=%s loss=%.6f" % (dist.get_backend(), float(loss)))
 dist.destroy_process_group()
