@@ -256,7 +256,7 @@ def main():
       except Exception as e:     # auxiliary measurements must not cost the headline line
         sys.stderr.write("bench: auxiliary timings failed: %r\n" % (e,))
         os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
-    if rank == 0 and world == 1:
+    if rank == 0:       # the dominant kernel is the same on every rank at any N (replicated cost assembly at B <= 64)
       try:
         kt, K = time_cost_kernel(t)
         B, T, J = SHAPE["B"], SHAPE["T"], SHAPE["J"]
@@ -294,7 +294,7 @@ def main():
       except Exception as e:
         sys.stderr.write("bench: roofline block failed: %r\n" % (e,))
       try:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(inp)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
       except Exception as e:
@@ -302,6 +302,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()          # rank 0 measured the roofline block after the timed region: leave together
         dist.destroy_process_group()
 
 

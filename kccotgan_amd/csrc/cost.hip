@@ -321,6 +321,8 @@ static int run_cost(CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J
     }
     const bool partial_only = (flags & KCCOT_COST_PARTIAL_ONLY) != 0;
     if (mfma) return run_gram(cb, loss3, K, sc, T, J, ws, ws_bytes, partial_only, st);
+    if (!(flags & KCCOT_COST_FORCE_DIRECT) && !partial_only && gram_tiled_eligible(cb, K, loss3))
+        return run_gram_tiled(cb, K, sc, T, J, ws, ws_bytes, st);
     if (!(flags & KCCOT_COST_FORCE_DIRECT) && !partial_only && gram_blocked_eligible(cb, K, loss3))
         return run_gram_blocked(cb, K, sc, T, J, ws, ws_bytes, st);
     return run_direct(cb, K, sc, T, J, ws, ws_bytes, partial_only, st);
@@ -362,7 +364,9 @@ extern "C" size_t kccot_pairwise_cost3_workspace_bytes(int B, int64_t K) {
     int Bs[3] = {B, B, B}, same[3] = {0, 1, 1};
     size_t a = plan_direct(3, Bs, Bs, same, K).ws_bytes;
     size_t b = plan_gram(K).ws_bytes;
-    return a > b ? a : b;
+    size_t c = gram_tiled_workspace_bytes(B, K);
+    a = a > b ? a : b;
+    return a > c ? a : c;
 }
 
 extern "C" int kccot_pairwise_cost3_f32(const float* real, const float* fake, int B, int64_t K, float sc,
