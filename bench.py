@@ -159,14 +159,21 @@ def main():
         if os.environ.get("KCCOT_BENCH_EAGER") != "1":
             # the collectives stay RCCL calls; the two compute segments between them replay as hipGraphs
             # (kccotgan_amd/graph.py: the eager sharded step is host-bound, 0.36 ms of Python for 0.22 ms of kernels)
+            gstep = None
             try:
                 from kccotgan_amd.graph import GraphedShardedStep
                 gstep = GraphedShardedStep(shard, SC)
-                step = lambda: gstep()
-                mode = "RCCL all-gathers + hipGraph replay of the two compute segments"
             except Exception as e:
-                sys.stderr.write("bench: sharded graph capture failed (%r); timing eager launches\n" % (e,))
+                sys.stderr.write("bench: sharded graph capture failed on rank %d (%r)\n" % (rank, e))
                 torch.cuda.synchronize()
+            # every rank must issue the same collectives: use the graphed step only if ALL ranks captured it
+            flag = torch.tensor([1 if gstep is not None else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag) == 1:
+                step = lambda: gstep()
+                mode = "RCCL all-gathers + hipGraph replay of the compute between them"
+            elif rank == 0:
+                sys.stderr.write("bench: timing eager launches on all ranks\n")
     elif os.environ.get("KCCOT_BENCH_EAGER") == "1":
         step = lambda: loss_step(G, t)
     else:
@@ -219,7 +226,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: Moving-MNIST shape B=64,T=30,64x64x1, J=8, 100 Sinkhorn iters, "
                                "compute_sinkhorn_loss fwd+bwd", "global_batch": SHAPE["B"],
-                   "parallelism": "single GPU" if world == 1 else "batch-sharded x%d, all-gather, replicated Sinkhorn" % world,
+                   "parallelism": "single GPU" if world == 1 else "batch-sharded x%d: RCCL all-gather of the shards, replicated cost assembly (B <= 64) and Sinkhorn, per-rank gradients" % world,
                    "sinkhorn_iters": nits, "sinkhorn_iters_executed": nexec, "sinkhorn_exact_shortcut": "off",
                    "launch": mode, "loss": float(loss)},
     }
