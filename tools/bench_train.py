@@ -14,11 +14,16 @@ def run(kernel, iters=5, B=64):
     tr = KCCOTTrainer(B, total_time_steps=30, int_time_steps=5, x_height=64, x_width=64, channels=1, kernel=kernel,
                       device="cuda:0")
     x = torch.rand(B, 64, 30, 64, 1, device="cuda:0")
+    t0 = time.perf_counter()
     tr.train_iteration(x)
     torch.cuda.synchronize()
+    print("warm-up iteration (MIOpen solver selection included): %.1f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    for _ in range(iters):
+    for i in range(iters):
         pm, loss = tr.train_iteration(x)
+        if i == 0:
+            torch.cuda.synchronize()
+            print("first timed iteration: %.2f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     return dict(kernel=kernel, ms_per_train_step=dt * 1e3, train_steps_per_sec=1 / dt, pm=float(pm), loss=float(loss))
