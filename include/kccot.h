@@ -233,6 +233,8 @@ int kccot_rbf_mmd_bwd_f32(const float* K3, int B, float gamma, const float* gmmd
 #define KCCOT_SMOOTH_W 4u
 #define KCCOT_SMOOTH_NO_DIVIDE 16u
 #define KCCOT_SMOOTH_EXTERNAL_MAX 32u
+#define KCCOT_SMOOTH_STATS_ONLY 64u      /* kccot_smooth_bwd_sharded_f32 only */
+#define KCCOT_SMOOTH_EXTERNAL_STATS 128u /* kccot_smooth_bwd_sharded_f32 only */
 size_t kccot_smooth_workspace_bytes(int B, int H, int T, int W, int C);
 int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W, int C, float sigma,
                          int radius, unsigned axes_flags, float* out, float* max_inout,
@@ -241,6 +243,16 @@ int kccot_smooth_bwd_f32(const float* gout, const float* out, const float* max_i
                          int B, int H, int T, int W, int C, float sigma, int radius,
                          unsigned axes_flags, float* din,
                          void* ws, size_t ws_bytes, kccot_stream_t stream);
+/* Backward for the batch-sharded caller (every rank holds B/G samples, `max_in` is the all-reduced(MAX) global maximum
+ * the forward divided by).  The adjoint of the division by the GLOBAL maximum needs two sums over the whole batch,
+ * stats = {sum(gout * out), number of elements with out == 1}:
+ *   flags | KCCOT_SMOOTH_STATS_ONLY      writes this rank's two sums to stats_inout[0..1] (din is not touched);
+ *   the caller all-reduces(SUM) them;
+ *   flags | KCCOT_SMOOTH_EXTERNAL_STATS  reads the global sums from stats_inout and writes din. */
+int kccot_smooth_bwd_sharded_f32(const float* gout, const float* out, const float* max_in, float* stats_inout,
+                                 int B, int H, int T, int W, int C, float sigma, int radius,
+                                 unsigned axes_flags, float* din,
+                                 void* ws, size_t ws_bytes, kccot_stream_t stream);
 
 #ifdef __cplusplus
 }

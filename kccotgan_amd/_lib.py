@@ -17,6 +17,7 @@ EINVAL, EUNSUPPORTED, EWORKSPACE = -1, -2, -3
 COST_SAME, COST_FORCE_DIRECT, COST_FORCE_MFMA, COST_PARTIAL_ONLY = 1, 2, 4, 8
 STOP_COUNT, STOP_INDEX = 0, 1
 SMOOTH_T, SMOOTH_H, SMOOTH_W, SMOOTH_NO_DIVIDE, SMOOTH_EXTERNAL_MAX = 1, 2, 4, 16, 32
+SMOOTH_STATS_ONLY, SMOOTH_EXTERNAL_STATS = 64, 128
 
 _c = ctypes
 _fp = _c.c_void_p      # device pointers travel as plain addresses
@@ -59,6 +60,7 @@ SIGNATURES = {
     "kccot_smooth_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "kccot_smooth_fwd_f32": (_i, [_fp, _i, _i, _i, _i, _i, _f, _i, _u, _fp, _fp, _fp, _sz, _fp]),
     "kccot_smooth_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _i, _u, _fp, _fp, _sz, _fp]),
+    "kccot_smooth_bwd_sharded_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _i, _u, _fp, _fp, _sz, _fp]),
 }
 
 

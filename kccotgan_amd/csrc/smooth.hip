@@ -761,10 +761,16 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
     return 0;
 }
 
-extern "C" int kccot_smooth_bwd_f32(const float* gout, const float* out, const float* max_in, int B, int H, int T,
-                                    int W, int C, float sigma, int radius, unsigned flags, float* din, void* ws,
-                                    size_t ws_bytes, kccot_stream_t stream) {
-    int rc = smooth_check("smooth_bwd", gout, din, B, H, T, W, C, sigma, radius, flags);
+// stats_ext: null = the normalisation adjoint's two batch sums {sum(g * out), #(out == 1)} are computed and used
+// here; with KCCOT_SMOOTH_STATS_ONLY they are written to stats_ext and nothing else happens; with
+// KCCOT_SMOOTH_EXTERNAL_STATS they are READ from stats_ext (the batch-sharded caller has all-reduced(SUM) them).
+static int smooth_bwd_impl(const float* gout, const float* out, const float* max_in, float* stats_ext, int B, int H, int T,
+                           int W, int C, float sigma, int radius, unsigned flags, float* din, void* ws,
+                           size_t ws_bytes, kccot_stream_t stream) {
+    const bool stats_only = (flags & KCCOT_SMOOTH_STATS_ONLY) != 0, stats_in = (flags & KCCOT_SMOOTH_EXTERNAL_STATS) != 0;
+    if (stats_only && stats_in) return fail(KCCOT_EINVAL, "smooth_bwd: STATS_ONLY and EXTERNAL_STATS are exclusive");
+    if ((stats_only || stats_in) && !stats_ext) return fail(KCCOT_EINVAL, "smooth_bwd: null stats pointer");
+    int rc = smooth_check("smooth_bwd", gout, stats_only ? const_cast<float*>(gout) : din, B, H, T, W, C, sigma, radius, flags);
     if (rc) return rc;
     if (!out || !max_in) return fail(KCCOT_EINVAL, "smooth_bwd: null pointer");
     const size_t need = kccot_smooth_workspace_bytes(B, H, T, W, C);
@@ -784,11 +790,18 @@ extern "C" int kccot_smooth_bwd_f32(const float* gout, const float* out, const f
     float* ds = (na % 2 == 0) ? din : tmp;
     const bool wide = (n % 4 == 0) && ((uintptr_t)gout % 16 == 0) && ((uintptr_t)out % 16 == 0) && nb >= 2048;
     const int64_t nparts = wide ? 2048 : nb;
-    if (wide) hipLaunchKernelGGL(maxnorm_bwd_partial_v4, dim3(2048), dim3(256), 0, st, gout, out, n / 4, pdot, pcnt);
-    else hipLaunchKernelGGL(maxnorm_bwd_partial, dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, pdot, pcnt);
-    if ((rc = launch_status("maxnorm_bwd_partial"))) return rc;
-    hipLaunchKernelGGL(maxnorm_bwd_combine, dim3(1), dim3(1024), 0, st, (const float*)pdot, (const float*)pcnt, nparts, res);
-    if ((rc = launch_status("maxnorm_bwd_combine"))) return rc;
+    if (stats_in) {
+        res = stats_ext;                                       // the global sums: every kernel below reads res[0], res[1]
+    } else {
+        if (stats_only) res = stats_ext;
+        if (wide) hipLaunchKernelGGL(maxnorm_bwd_partial_v4, dim3(2048), dim3(256), 0, st, gout, out, n / 4, pdot, pcnt);
+        else hipLaunchKernelGGL(maxnorm_bwd_partial, dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, pdot, pcnt);
+        if ((rc = launch_status("maxnorm_bwd_partial"))) return rc;
+        hipLaunchKernelGGL(maxnorm_bwd_combine, dim3(1), dim3(1024), 0, st, (const float*)pdot, (const float*)pcnt, nparts, res);
+        if ((rc = launch_status("maxnorm_bwd_combine"))) return rc;
+        if (stats_only) return 0;
+    }
+    float* scal = reinterpret_cast<float*>(p + 2 * align_up((size_t)nb * sizeof(float), 256));   // workspace scalars {.., .., .., .., 1, 0, 0}
     const unsigned axes = flags & (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W);
     if ((radius == 3 || radius == 4) && !getenv("KCCOT_SMOOTH_NO_STREAM") &&
         (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W))) {
@@ -811,7 +824,7 @@ extern "C" int kccot_smooth_bwd_f32(const float* gout, const float* out, const f
             if (w1) {
                 if ((rc = launch_w1(din, tmp, n, W, radius, true, tp, st))) return rc;
             } else {
-                float* one = res + 4;                           // scalar slots behind {dot, ties}: {1, 0, 0}
+                float* one = scal + 4;                          // scalar slots behind {dot, ties}: {1, 0, 0}
                 if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x3f800000, 1, st) != hipSuccess ||
                     hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one + 1), 0, 2, st) != hipSuccess)
                     return fail(KCCOT_EINVAL, "smooth_bwd: memset failed");
@@ -830,7 +843,7 @@ extern "C" int kccot_smooth_bwd_f32(const float* gout, const float* out, const f
     if (plane_eligible(T, W, C, radius, na) && getenv("KCCOT_SMOOTH_FUSED_BWD")) {
         PlaneArgs pa{};
         pa.in = gout; pa.out_fwd = out; pa.out = din; pa.mx = max_in; pa.res = res;
-        pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C; pa.axes = flags; pa.tp = tp;
+        pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C; pa.axes = axes; pa.tp = tp;
         pa.hseg = plane_hseg(B, H, (flags & KCCOT_SMOOTH_H) != 0);
         return launch_plane(pa, radius, true, dim3((H + pa.hseg - 1) / pa.hseg, B), st);
     }
@@ -845,4 +858,20 @@ extern "C" int kccot_smooth_bwd_f32(const float* gout, const float* out, const f
         src = dst;
     }
     return 0;
+}
+
+extern "C" int kccot_smooth_bwd_f32(const float* gout, const float* out, const float* max_in, int B, int H, int T,
+                                    int W, int C, float sigma, int radius, unsigned flags, float* din, void* ws,
+                                    size_t ws_bytes, kccot_stream_t stream) {
+    if (flags & (KCCOT_SMOOTH_STATS_ONLY | KCCOT_SMOOTH_EXTERNAL_STATS))
+        return fail(KCCOT_EINVAL, "smooth_bwd: the stats flags belong to kccot_smooth_bwd_sharded_f32");
+    return smooth_bwd_impl(gout, out, max_in, nullptr, B, H, T, W, C, sigma, radius, flags, din, ws, ws_bytes, stream);
+}
+
+extern "C" int kccot_smooth_bwd_sharded_f32(const float* gout, const float* out, const float* max_in, float* stats_inout,
+                                            int B, int H, int T, int W, int C, float sigma, int radius, unsigned flags,
+                                            float* din, void* ws, size_t ws_bytes, kccot_stream_t stream) {
+    if (!(flags & (KCCOT_SMOOTH_STATS_ONLY | KCCOT_SMOOTH_EXTERNAL_STATS)))
+        return fail(KCCOT_EINVAL, "smooth_bwd_sharded: give KCCOT_SMOOTH_STATS_ONLY or KCCOT_SMOOTH_EXTERNAL_STATS");
+    return smooth_bwd_impl(gout, out, max_in, stats_inout, B, H, T, W, C, sigma, radius, flags, din, ws, ws_bytes, stream);
 }

@@ -80,6 +80,38 @@ def run(rank, world, port, shape, seed, regime, device, use_hip, out_path):
     dist.destroy_process_group()
 
 
+def smooth_case(seed):
+    """Videos whose global maximum sits in ONE shard, and an upstream gradient, both functions of the global index."""
+    rng = np.random.default_rng(100 + seed)
+    x = rng.random((4, 16, 12, 16, 1), dtype=np.float32)
+    x[3] *= 1.5                               # the arg-max lives in the last sample (rank world-1)
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    return x, g
+
+
+def run_smooth(rank, world, port, seed, device, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kccotgan_amd.data_utils import KernelSmoothing
+    x, g = smooth_case(seed)
+    Bl = x.shape[0] // world
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    ks = KernelSmoothing(6, 6, sharded=True)
+    res = {}
+    for name, fn in (("t", ks.temporal_convolution), ("3d", ks.gaussian_convolution3D)):
+        xt = torch.from_numpy(x[sl]).to(device).requires_grad_(True)
+        out = fn(xt, 1.7)
+        out.backward(torch.from_numpy(g[sl]).to(device))
+        res["out_" + name] = out.detach().cpu().numpy()
+        res["din_" + name] = xt.grad.cpu().numpy()
+    np.savez(out_path % rank, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     a = sys.argv
-    run(int(a[1]), int(a[2]), int(a[3]), a[4], int(a[5]), a[6], a[7], a[8] == "hip", a[9])
+    if a[8] == "smooth":
+        run_smooth(int(a[1]), int(a[2]), int(a[3]), int(a[5]), a[7], a[9])
+    else:
+        run(int(a[1]), int(a[2]), int(a[3]), a[4], int(a[5]), a[6], a[7], a[8] == "hip", a[9])

@@ -98,3 +98,26 @@ def test_sharded_hip_equals_single_gpu(shape, seed, regime, protocol, tmp_path):
             # entries of O(1e3) that moves the plan (hence the gradients) at the 1e-4..1e-3 level --
             # the same fp32 conditioning that sets the 2e-3 gradient tolerance against the fp64 oracle
             np.testing.assert_allclose(out["d" + k].reshape(Bl, -1), want, rtol=0, atol=2e-3 * np.abs(g).max(), err_msg=k)
+
+
+@pytest.mark.gpu
+def test_sharded_smoothing_equals_unsharded(tmp_path):
+    """KernelSmoothing(sharded=True) on two ranks (gloo, one GPU): all-reduced(MAX) global maximum in the forward,
+    all-reduced(SUM) normalisation sums in the backward -- against the unsharded call on the whole batch.  The
+    arg-max sits in rank 1's shard, so rank 0's gradient carries no arg-max term but its outputs are divided by
+    rank 1's maximum."""
+    import dist_worker
+    from kccotgan_amd.data_utils import KernelSmoothing
+    res = launch(2, "none", 0, "none", "cuda:0", "smooth", tmp_path)
+    x, g = dist_worker.smooth_case(0)
+    ks = KernelSmoothing(6, 6)
+    for name, fn in (("t", ks.temporal_convolution), ("3d", ks.gaussian_convolution3D)):
+        xt = torch.from_numpy(x).to("cuda:0").requires_grad_(True)
+        out = fn(xt, 1.7)
+        out.backward(torch.from_numpy(g).to("cuda:0"))
+        want_out, want_din = out.detach().cpu().numpy(), xt.grad.cpu().numpy()
+        got_out = np.concatenate([r["out_" + name] for r in res])
+        got_din = np.concatenate([r["din_" + name] for r in res])
+        assert float(got_out.max()) == 1.0 and float(res[0]["out_" + name].max()) < 1.0
+        np.testing.assert_array_equal(got_out, want_out)                  # same maximum, same division
+        np.testing.assert_allclose(got_din, want_din, rtol=0, atol=2e-6 * np.abs(want_din).max())
