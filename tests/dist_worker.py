@@ -109,9 +109,30 @@ def run_smooth(rank, world, port, seed, device, out_path):
     dist.destroy_process_group()
 
 
+def run_train(rank, world, port, seed, device, out_path):
+    """One data-parallel training iteration (disc + gen step) of the small trainer configuration on `world` ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kccotgan_amd import gan
+    from kccotgan_amd.kernel_train import KCCOTTrainer
+    gan._NATIVE = {"convlstm", "deconv", "dconv"}            # conservative convolution mode, as the single-GPU trainer test
+    Bl, H, W, C, T, iT = 2, 64, 64, 1, 6, 2
+    tr = KCCOTTrainer(Bl, total_time_steps=T, int_time_steps=iT, x_height=H, x_width=W, channels=C, kernel="1d", warmup=10,
+                      device=device, seed=seed + rank)       # different initial weights per rank: the constructor broadcasts rank 0's
+    x = torch.from_numpy(np.random.default_rng(7).random((Bl * world, H, T, W, C), dtype=np.float32))[rank * Bl:(rank + 1) * Bl]
+    p0 = torch.cat([p.detach().reshape(-1) for p in tr.g_params + tr.d_params]).cpu().numpy()
+    pm, loss = tr.train_iteration(x.to(device), 4.0)
+    p1 = torch.cat([p.detach().reshape(-1) for p in tr.g_params + tr.d_params]).cpu().numpy()
+    np.savez(out_path % rank, p0=p0, p1=p1, pm=np.array(float(pm)), loss=np.array(float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     a = sys.argv
-    if a[8] == "smooth":
+    if a[8] == "train":
+        run_train(int(a[1]), int(a[2]), int(a[3]), int(a[5]), a[7], a[9])
+    elif a[8] == "smooth":
         run_smooth(int(a[1]), int(a[2]), int(a[3]), int(a[5]), a[7], a[9])
     else:
         run(int(a[1]), int(a[2]), int(a[3]), a[4], int(a[5]), a[6], a[7], a[8] == "hip", a[9])

@@ -121,3 +121,17 @@ def test_sharded_smoothing_equals_unsharded(tmp_path):
         assert float(got_out.max()) == 1.0 and float(res[0]["out_" + name].max()) < 1.0
         np.testing.assert_array_equal(got_out, want_out)                  # same maximum, same division
         np.testing.assert_allclose(got_din, want_din, rtol=0, atol=2e-6 * np.abs(want_din).max())
+
+
+@pytest.mark.gpu
+def test_data_parallel_trainer_keeps_replicas_identical(tmp_path):
+    """Two ranks (gloo, one GPU), one training iteration each on its half of a batch of four, kernel smoothing on:
+    the constructor broadcasts rank 0's weights, the loss is the replicated GLOBAL-batch divergence, parameter
+    gradients are all-reduced(SUM) -- so both replicas hold bit-identical weights before and after the step, the
+    weights move, and both report the same finite loss and pM."""
+    res = launch(2, "none", 3, "none", "cuda:0", "train", tmp_path)
+    a, b = res
+    assert np.array_equal(a["p0"], b["p0"]) and np.array_equal(a["p1"], b["p1"])
+    assert not np.array_equal(a["p0"], a["p1"]) and np.isfinite(a["p1"]).all()
+    assert float(a["loss"]) == float(b["loss"]) and float(a["pm"]) == float(b["pm"])
+    assert np.isfinite(float(a["loss"])) and np.isfinite(float(a["pm"]))
