@@ -161,8 +161,13 @@ def main():
             # (kccotgan_amd/graph.py: the eager sharded step is host-bound, 0.36 ms of Python for 0.22 ms of kernels)
             gstep = None
             try:
-                from kccotgan_amd.graph import GraphedShardedStep
-                gstep = GraphedShardedStep(shard, SC)
+                if os.environ.get("KCCOT_DIST_PROTOCOL") == "ksplit":
+                    # opt-in: contraction-sharded protocol (all-to-all into K-slices, all-reduced Gram sums)
+                    from kccotgan_amd.graph import GraphedKSplitStep
+                    gstep = GraphedKSplitStep(shard, SC)
+                else:
+                    from kccotgan_amd.graph import GraphedShardedStep
+                    gstep = GraphedShardedStep(shard, SC)
             except Exception as e:
                 sys.stderr.write("bench: sharded graph capture failed on rank %d (%r)\n" % (rank, e))
                 torch.cuda.synchronize()
@@ -226,7 +231,10 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: Moving-MNIST shape B=64,T=30,64x64x1, J=8, 100 Sinkhorn iters, "
                                "compute_sinkhorn_loss fwd+bwd", "global_batch": SHAPE["B"],
-                   "parallelism": "single GPU" if world == 1 else "batch-sharded x%d: RCCL all-gather of the shards, replicated cost assembly (B <= 64) and Sinkhorn, per-rank gradients" % world,
+                   "parallelism": "single GPU" if world == 1 else (
+                       ("contraction-sharded x%d: all-to-all into K-slices, all-reduced fp64 Gram sums, replicated Sinkhorn, all-to-all back" % world)
+                       if os.environ.get("KCCOT_DIST_PROTOCOL") == "ksplit" else
+                       ("batch-sharded x%d: RCCL all-gather of the shards, replicated cost assembly (B <= 64) and Sinkhorn, per-rank gradients" % world)),
                    "sinkhorn_iters": nits, "sinkhorn_iters_executed": nexec, "sinkhorn_exact_shortcut": "off",
                    "launch": mode, "loss": float(loss)},
     }

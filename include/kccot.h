@@ -41,6 +41,10 @@ extern "C" {
 #define KCCOT_COST_FORCE_DIRECT 2u /* use the direct-difference kernel (exact (x-y)^2 form)   */
 #define KCCOT_COST_FORCE_MFMA 4u   /* use the stacked-Gram f32-MFMA kernel                    */
 #define KCCOT_COST_PARTIAL_ONLY 8u /* profiling aid: launch only the K-split partial kernel   */
+#define KCCOT_COST_GRAM_SUMS_ONLY 16u /* kccot_pairwise_cost3_f32: stop after the fp64 Gram sums (and the causal sums)  */
+                                      /* are in the workspace -- nothing is written to C3                               */
+#define KCCOT_COST_FROM_GRAM_SUMS 32u /* kccot_pairwise_cost3_f32: only the finalize step, from the sums left in the    */
+                                      /* SAME workspace by a GRAM_SUMS_ONLY call (real / fake are not read)             */
                                    /* (the dominant one); C_out is NOT written                */
 
 /* Sinkhorn stop modes */
@@ -79,6 +83,13 @@ int kccot_pairwise_cost3_f32(const float* real, const float* fake, int B, int64_
                              const float* m_real, const float* m_fake, int T, int J,
                              unsigned flags, float* C3,
                              void* ws, size_t ws_bytes, kccot_stream_t stream);
+
+/* The two flags above split the call for a caller that shards the CONTRACTION over ranks (every rank holds all B
+ * samples but only a slice [B, Ks] of the features): each rank runs GRAM_SUMS_ONLY on its slice, the callers
+ * all-reduce(SUM) the fp64 Gram sums in place, and FROM_GRAM_SUMS turns them into the three cost matrices.
+ * kccot_pairwise_cost3_gram_sums_span reports where the sums sit in the workspace (byte offset, number of doubles);
+ * 0 doubles = this (B, K) has no Gram path (use the other protocol).  Both calls must use the same B, K, workspace. */
+int kccot_pairwise_cost3_gram_sums_span(int B, int64_t K, size_t* byte_offset, size_t* n_doubles);
 
 /* Row blocks [row_count, B] of the same three matrices for the batch-sharded caller (kccotgan_amd/dist.py: rank g
  * owns samples [row_begin, row_begin+row_count) of the gathered batch): one launch of the exact direct-difference

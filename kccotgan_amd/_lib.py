@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libkccot.so")
 EINVAL, EUNSUPPORTED, EWORKSPACE = -1, -2, -3
 
 COST_SAME, COST_FORCE_DIRECT, COST_FORCE_MFMA, COST_PARTIAL_ONLY = 1, 2, 4, 8
+COST_GRAM_SUMS_ONLY, COST_FROM_GRAM_SUMS = 16, 32
 STOP_COUNT, STOP_INDEX = 0, 1
 SMOOTH_T, SMOOTH_H, SMOOTH_W, SMOOTH_NO_DIVIDE, SMOOTH_EXTERNAL_MAX = 1, 2, 4, 16, 32
 SMOOTH_STATS_ONLY, SMOOTH_EXTERNAL_STATS = 64, 128
@@ -31,6 +32,7 @@ SIGNATURES = {
     "kccot_pairwise_cost_f32": (_i, [_fp, _fp, _i, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _u, _fp, _fp, _sz, _fp]),
     "kccot_pairwise_cost3_workspace_bytes": (_sz, [_i, _i64]),
     "kccot_pairwise_cost3_f32": (_i, [_fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _u, _fp, _fp, _sz, _fp]),
+    "kccot_pairwise_cost3_gram_sums_span": (_i, [_i, _i64, _c.POINTER(_sz), _c.POINTER(_sz)]),
     "kccot_pairwise_cost3_rows_workspace_bytes": (_sz, [_i, _i, _i64]),
     "kccot_pairwise_cost3_rows_f32": (_i, [_fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _sz, _fp]),
     "kccot_pairwise_cost3_bwd_workspace_bytes": (_sz, [_i, _i64]),

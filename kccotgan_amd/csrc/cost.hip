@@ -320,9 +320,14 @@ static int run_cost(CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J
         mfma = gram_preferred(cb, K, loss3);
     }
     const bool partial_only = (flags & KCCOT_COST_PARTIAL_ONLY) != 0;
-    if (mfma) return run_gram(cb, loss3, K, sc, T, J, ws, ws_bytes, partial_only, st);
+    // split at the fp64 Gram sums for the contraction-sharded caller (include/kccot.h)
+    const int stage = (flags & KCCOT_COST_GRAM_SUMS_ONLY) ? 1 : ((flags & KCCOT_COST_FROM_GRAM_SUMS) ? 2 : 0);
+    if (stage && (partial_only || (flags & KCCOT_COST_FORCE_DIRECT) || !loss3))
+        return fail(KCCOT_EINVAL, "pairwise_cost: the Gram-sum split applies to kccot_pairwise_cost3_f32 on the Gram paths only");
+    if (mfma) return run_gram(cb, loss3, K, sc, T, J, ws, ws_bytes, partial_only, st, stage);
     if (!(flags & KCCOT_COST_FORCE_DIRECT) && !partial_only && gram_tiled_eligible(cb, K, loss3))
-        return run_gram_tiled(cb, K, sc, T, J, ws, ws_bytes, st);
+        return run_gram_tiled(cb, K, sc, T, J, ws, ws_bytes, st, stage);
+    if (stage) return fail(KCCOT_EUNSUPPORTED, "pairwise_cost3: no Gram path for B=%d K=%lld (Gram-sum split)", cb.p[0].Bx, (long long)K);
     if (!(flags & KCCOT_COST_FORCE_DIRECT) && !partial_only && gram_blocked_eligible(cb, K, loss3))
         return run_gram_blocked(cb, K, sc, T, J, ws, ws_bytes, st);
     return run_direct(cb, K, sc, T, J, ws, ws_bytes, partial_only, st);
@@ -367,6 +372,17 @@ extern "C" size_t kccot_pairwise_cost3_workspace_bytes(int B, int64_t K) {
     size_t c = gram_tiled_workspace_bytes(B, K);
     a = a > b ? a : b;
     return a > c ? a : c;
+}
+
+extern "C" int kccot_pairwise_cost3_gram_sums_span(int B, int64_t K, size_t* byte_offset, size_t* n_doubles) {
+    if (!byte_offset || !n_doubles) return fail(KCCOT_EINVAL, "gram_sums_span: null pointer");
+    *byte_offset = 0; *n_doubles = 0;
+    if (B <= 0 || K <= 0 || K % 4 != 0 || K < 256) return 0;
+    const char* e = getenv("KCCOT_GRAM_F32");
+    const bool x3 = !(e && atoi(e) == 1);
+    if (B <= 64) gram_sums_span(K, byte_offset, n_doubles);
+    else if (x3 && B % 128 == 0 && B <= 4096 && !getenv("KCCOT_COST_NO_TILED")) gram_tiled_sums_span(B, K, byte_offset, n_doubles);
+    return 0;
 }
 
 extern "C" int kccot_pairwise_cost3_f32(const float* real, const float* fake, int B, int64_t K, float sc,

@@ -118,11 +118,14 @@ bool gram_eligible(const CostBatch& cb, int64_t K, bool loss3);
 bool gram_preferred(const CostBatch& cb, int64_t K, bool loss3);
 GramPlan plan_gram(int64_t K);
 int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J, void* ws,
-             size_t ws_bytes, bool partial_only, hipStream_t st);
+             size_t ws_bytes, bool partial_only, hipStream_t st, int stage = 0);
 // cost_tiled.hip: batches that are multiples of 128 -- one Gram of the [real ; fake - real] stack in 128 x 128 tiles
 bool gram_tiled_eligible(const CostBatch& cb, int64_t K, bool loss3);
 size_t gram_tiled_workspace_bytes(int B, int64_t K);
-int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st);
+int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st,
+                   int stage = 0);
+void gram_tiled_sums_span(int B, int64_t K, size_t* off, size_t* n);
+void gram_sums_span(int64_t K, size_t* off, size_t* n);
 bool gram_blocked_eligible(const CostBatch& cb, int64_t K, bool loss3);
 int run_gram_blocked(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st);
 

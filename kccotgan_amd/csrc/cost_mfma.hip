@@ -763,8 +763,15 @@ static unsigned gram_mask(int mode, int n1, int n2) {
     return m;
 }
 
+void gram_sums_span(int64_t K, size_t* off, size_t* n) {
+    const GramPlan pl = plan_gram(K);
+    *off = pl.gpart_bytes;
+    *n = GRAM_ELEMS;
+}
+
+// stage 0: everything; 1: stop after the fp64 Gram sums and the causal sums are in the workspace; 2: finalize only
 int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J, void* ws,
-             size_t ws_bytes, bool partial_only, hipStream_t st) {
+             size_t ws_bytes, bool partial_only, hipStream_t st, int stage) {
     GramPlan pl = plan_gram(K);
     if (!ws || ws_bytes < pl.ws_bytes)
         return fail(KCCOT_EWORKSPACE, "pairwise_cost(mfma): workspace %zu < required %zu", ws_bytes, pl.ws_bytes);
@@ -815,6 +822,12 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     int ncausal = nslot * cp.nti * cp.ntj;                  // tiles still to be done by gram_reduce's extra workgroups
     ga.nchunk = pl.nchunk; ga.ntiles = 0; ga.cp = cp;
     int split_mode = (ga.mask == 0x3FFu) ? GRAM_SPLIT_89 : GRAM_SPLIT_NONE;
+    if (stage == 2) {
+        gf.gsum = gsum; gf.caus = cp.caus; gf.mode = mode; gf.sc = sc; gf.T = T; gf.J = J;
+        hipLaunchKernelGGL(gram_finalize, dim3((gf.B2 + CAUSAL_TILE - 1) / CAUSAL_TILE, (gf.B1 + CAUSAL_TILE - 1) / CAUSAL_TILE, nout),
+                           dim3(256), 0, st, gf);
+        return launch_status("gram_finalize");
+    }
     if (ga.mask == 0x3FFu && gram_use_x3()) {
         const char* e = getenv("KCCOT_GRAM_WS");   // =0: the single-role x3 kernel (A/B)
         if (e && atoi(e) == 0) hipLaunchKernelGGL(gram128_partial_x3, dim3(pl.nchunk), dim3(256), 0, st, ga);
@@ -835,7 +848,7 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 64 + ncausal), dim3(1024), 0, st,
                        (const float*)ga.gpart, pl.nchunk, ga.mask, split_mode, gsum, cp);
     rc = launch_status("gram_reduce");
-    if (rc) return rc;
+    if (rc || stage == 1) return rc;
     gf.gsum = gsum; gf.caus = cp.caus; gf.mode = mode; gf.sc = sc; gf.T = T; gf.J = J;
     hipLaunchKernelGGL(gram_finalize, dim3((gf.B2 + CAUSAL_TILE - 1) / CAUSAL_TILE, (gf.B1 + CAUSAL_TILE - 1) / CAUSAL_TILE, nout),
                        dim3(256), 0, st, gf);

@@ -316,6 +316,13 @@ static TilePlan plan_tiled(int B, int64_t K) {
     return pl;
 }
 
+// where the fp64 sums sit in the workspace (the all-reducing caller's view)
+void gram_tiled_sums_span(int B, int64_t K, size_t* off, size_t* n) {
+    const TilePlan pl = plan_tiled(B, K);
+    *off = pl.part_bytes;
+    *n = (size_t)pl.npairs * TELEMS;
+}
+
 size_t gram_tiled_workspace_bytes(int B, int64_t K) {
     if (B < TP || B % TP != 0 || B > 4096) return 0;
     return plan_tiled(B, K).ws_bytes;
@@ -330,7 +337,8 @@ bool gram_tiled_eligible(const CostBatch& cb, int64_t K, bool loss3) {
     return ((uintptr_t)cb.p[0].x % 16 == 0) && ((uintptr_t)cb.p[0].y % 16 == 0);
 }
 
-int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st) {
+int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st,
+                   int stage) {   // stage 0: everything; 1: stop after the fp64 sums; 2: finalize only
     const int B = cb.p[0].Bx;
     const TilePlan pl = plan_tiled(B, K);
     if (!ws || ws_bytes < pl.ws_bytes)
@@ -338,13 +346,16 @@ int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void*
     if (pl.nchunk > 65535) return fail(KCCOT_EUNSUPPORTED, "pairwise_cost3(tiled): %d chunks", pl.nchunk);
     float* part = static_cast<float*>(ws);
     double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.part_bytes);
-    TileArgs ta{cb.p[0].x, cb.p[0].y, B, pl.nt, pl.nchunk, K, pl.chunk, part};
-    hipLaunchKernelGGL(gram_tile_x3, dim3(pl.npairs * pl.nchunk), dim3(512), 0, st, ta);
-    int rc = launch_status("gram_tile_x3");
-    if (rc) return rc;
-    const int nvalid = (int)((K + pl.chunk - 1) / pl.chunk);
-    hipLaunchKernelGGL(gram_tile_reduce, dim3(TELEMS / 256, pl.npairs), dim3(256), 0, st, (const float*)part, pl.nchunk, nvalid, gsum);
-    if ((rc = launch_status("gram_tile_reduce"))) return rc;
+    int rc;
+    if (stage != 2) {
+        TileArgs ta{cb.p[0].x, cb.p[0].y, B, pl.nt, pl.nchunk, K, pl.chunk, part};
+        hipLaunchKernelGGL(gram_tile_x3, dim3(pl.npairs * pl.nchunk), dim3(512), 0, st, ta);
+        if ((rc = launch_status("gram_tile_x3"))) return rc;
+        const int nvalid = (int)((K + pl.chunk - 1) / pl.chunk);
+        hipLaunchKernelGGL(gram_tile_reduce, dim3(TELEMS / 256, pl.npairs), dim3(256), 0, st, (const float*)part, pl.nchunk, nvalid, gsum);
+        if ((rc = launch_status("gram_tile_reduce"))) return rc;
+        if (stage == 1) return 0;
+    }
     TileFin f{};
     f.gsum = gsum; f.B = B; f.nt = pl.nt; f.sc = sc; f.T = T; f.J = J;
     for (int p = 0; p < 3; ++p) { f.out[p] = cb.p[p].out; f.h[p] = cb.p[p].h1; f.M[p] = cb.p[p].M1; }

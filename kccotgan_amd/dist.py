@@ -156,6 +156,126 @@ class HipOps:
         return dfake, dhf, dhr, dmr, dmf
 
 
+# ---- contraction-sharded protocol ("ksplit") ------------------------------------------------------------------
+# Instead of gathering the whole batch on every rank, the [B/G, K] shards are all-to-all'ed into [B, K/G] slices:
+# every rank holds ALL samples but 1/G of the features.  The Gram kernels split K anyway, so rank g forms the fp64
+# Gram sums of its slice (KCCOT_COST_GRAM_SUMS_ONLY), the 80 KB (B <= 64) of sums are all-reduced(SUM), and the
+# finalize step (KCCOT_COST_FROM_GRAM_SUMS) gives every rank the full cost matrices -- the same arithmetic as one GPU,
+# with the K-chunks summed in a different grouping.  Backward: the video gradient of ALL samples on the rank's slice,
+# all-to-all back.  7/8 of a shard leaves a rank per tensor instead of 7 shards arriving, and the two HBM-heavy
+# kernels shrink with G.  Opt-in (protocol="ksplit" / KCCOT_DIST_PROTOCOL=ksplit) until it has been timed on a
+# multi-GPU node; needs K % G == 0, K/G % 4 == 0, K/G >= 256 and a Gram path for B (B <= 64 or B % 128 == 0).
+def ksplit_supported(B, K, world):
+    if world < 1 or K % world:
+        return False
+    Ks = K // world
+    if Ks % 4 or Ks < 256:
+        return False
+    import ctypes
+    off, cnt = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    check(lib.kccot_pairwise_cost3_gram_sums_span(B, Ks, ctypes.byref(off), ctypes.byref(cnt)), "gram_sums_span")
+    return cnt.value > 0
+
+
+def all_to_all_slices(t, group=None):
+    """[B/G, K] shard -> [B, K/G] slice: rows in global sample order, columns = this rank's K-range."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    Bl, K = t.shape
+    Ks = K // world
+    if dist.get_backend(group) != "nccl":        # gloo has no all_to_all: rehearsal through an all-gather
+        return t.contiguous() if world == 1 else all_gather_cat(t, group)[:, rank * Ks:(rank + 1) * Ks].contiguous()
+    send = t.reshape(Bl, world, Ks).transpose(0, 1).contiguous()          # [G, Bl, Ks]: chunk g goes to rank g
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return recv.reshape(world * Bl, Ks)
+
+
+def all_to_all_rows(t, group=None):
+    """Inverse of all_to_all_slices: [B, K/G] slice (all samples) -> [B/G, K] rows of this rank's samples."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B, Ks = t.shape
+    Bl = B // world
+    if dist.get_backend(group) != "nccl":
+        if world == 1:
+            return t.contiguous()
+        full = all_gather_cat(t.contiguous(), group).reshape(world, B, Ks)   # [source rank = K-range][sample][Ks]
+        return full[:, rank * Bl:(rank + 1) * Bl].transpose(0, 1).reshape(Bl, world * Ks).contiguous()
+    send = t.reshape(world, Bl, Ks).contiguous()                          # chunk g = the rows of rank g's samples
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)                       # recv[g] = K-range g of my samples
+    return recv.transpose(0, 1).reshape(Bl, world * Ks).contiguous()
+
+
+def _all_reduce_sum(t, group):
+    if dist.get_world_size(group) == 1:
+        return
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+class _KSplitLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, real_l, fake_l, h_fake_l, h_real_l, m_real_l, m_fake_l, sc, eps, L, group):
+        import ctypes
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        Bl = real_l.shape[0]
+        B = Bl * world
+        real_s = all_to_all_slices(real_l, group)
+        fake_s = all_to_all_slices(fake_l, group)
+        Ks = real_s.shape[1]
+        feats = all_gather_cat(torch.stack([h_fake_l, h_real_l, m_real_l, m_fake_l], dim=1), group)
+        h_fake, h_real, m_real, m_fake = (feats[:, i].contiguous() for i in range(4))
+        T, J = h_fake.shape[1], h_fake.shape[2]
+        dev = real_s.device
+        # a workspace of its own: the Gram sums must survive between the two calls (the shared scratch is reused)
+        wsb = int(lib.kccot_pairwise_cost3_workspace_bytes(B, Ks))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        off, cnt = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        check(lib.kccot_pairwise_cost3_gram_sums_span(B, Ks, ctypes.byref(off), ctypes.byref(cnt)), "gram_sums_span")
+        if cnt.value == 0:
+            raise NotImplementedError("ksplit protocol: no Gram path for B=%d, K/G=%d" % (B, Ks))
+        C3 = _lib.empty((3, B, B), torch.float32, dev)
+        args = (ptr(real_s), ptr(fake_s), B, Ks, sc, ptr(h_fake), ptr(h_real), ptr(m_real), ptr(m_fake), T, J)
+        check(lib.kccot_pairwise_cost3_f32(*args, _lib.COST_GRAM_SUMS_ONLY, ptr(C3), ws.data_ptr(), wsb, stream_of(real_s)),
+              "pairwise_cost3(gram sums)")
+        gsum = ws[off.value:off.value + 8 * cnt.value].view(torch.float64)
+        _all_reduce_sum(gsum, group)
+        check(lib.kccot_pairwise_cost3_f32(*args, _lib.COST_FROM_GRAM_SUMS, ptr(C3), ws.data_ptr(), wsb, stream_of(real_s)),
+              "pairwise_cost3(from gram sums)")
+        loss, saved = HipOps.divergence_fwd(C3, eps, L)
+        last_info["nits"], last_info["nits_executed"] = saved[3][:3], saved[3][3:]
+        ctx.saved_state = (saved, real_s, fake_s, h_fake, h_real, m_real, m_fake)
+        ctx.cfg = (sc, rank * Bl, Bl, group)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        saved, real_s, fake_s, h_fake, h_real, m_real, m_fake = ctx.saved_state
+        sc, row_begin, Bl, group = ctx.cfg
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("the loss path never differentiates w.r.t. real (kernel_train.py:252,289)")
+        dC3 = HipOps.divergence_bwd(saved, g.reshape(()))
+        B, Ks = real_s.shape
+        T, J = h_fake.shape[1], h_fake.shape[2]
+        # video gradient of ALL samples on this rank's K-slice, then back to the sample-sharded layout
+        dfake_s = _lib.empty((B, Ks), torch.float32, real_s.device)
+        ws, wsb = workspace(lib.kccot_pairwise_cost3_bwd_workspace_bytes(B, Ks), real_s)
+        check(lib.kccot_pairwise_cost3_bwd_f32(ptr(dC3), ptr(real_s), ptr(fake_s), B, Ks, sc, None, None, None, None, 1, 1,
+                                               ptr(dfake_s), None, None, None, None, ws, wsb, stream_of(real_s)),
+              "pairwise_cost3_bwd")
+        dfake = all_to_all_rows(dfake_s, group)
+        # feature gradients of this rank's samples (KB-sized products of dC3 with the gathered features)
+        dhf, dhr, dmr, dmf = (_lib.empty((Bl, T, J), torch.float32, real_s.device) for _ in range(4))
+        check(lib.kccot_pairwise_cost3_bwd_rows_f32(ptr(dC3), ptr(real_s), ptr(fake_s), B, Ks, sc, ptr(h_fake), ptr(h_real),
+                                                    ptr(m_real), ptr(m_fake), T, J, row_begin, Bl, None, ptr(dhf), ptr(dhr),
+                                                    ptr(dmr), ptr(dmf), None, 0, stream_of(real_s)), "pairwise_cost3_bwd_rows")
+        return None, dfake, dhf, dhr, dmr, dmf, None, None, None, None
+
+
 def all_gather_cat(t, group=None):
     """Concatenate the ranks' equally shaped tensors along dim 0.  RCCL handles device tensors
     directly; the gloo backend (CPU rehearsal) is staged through host memory."""
@@ -242,7 +362,7 @@ class _ShardedLoss(torch.autograd.Function):
 
 
 def sharded_sinkhorn_loss(f_real_l, f_fake_l, scaling_coef, h_fake_l, m_real_l, h_real_l, m_fake_l, group=None,
-                          ops=None, epsilon=1.0, L=100):
+                          ops=None, epsilon=1.0, L=100, protocol=None):
     """compute_sinkhorn_loss (gan_utils.py:204-227) of the GLOBAL batch from per-rank shards.
     Arguments are this rank's [B/G, ...] slices, in the reference's order h_fake, m_real, h_real,
     m_fake.  epsilon / L default to what the reference effectively runs (1.0, 100)."""
@@ -251,6 +371,16 @@ def sharded_sinkhorn_loss(f_real_l, f_fake_l, scaling_coef, h_fake_l, m_real_l, 
     cast = (lambda v: v.float()) if ops is HipOps else (lambda v: v)   # the HIP kernels are fp32
     flat = lambda v: cast(v.reshape(Bl, -1)).contiguous()
     feat = lambda v: cast(v).contiguous()
+    protocol = protocol or os.environ.get("KCCOT_DIST_PROTOCOL", "gather")
+    if protocol == "ksplit":
+        if ops is not HipOps:
+            raise ValueError("the ksplit protocol runs on the HIP ops only")
+        world = dist.get_world_size(group)
+        K = f_real_l.reshape(Bl, -1).shape[1]
+        if not ksplit_supported(Bl * world, K, world):
+            raise NotImplementedError("ksplit protocol: unsupported shape B=%d K=%d on %d ranks" % (Bl * world, K, world))
+        return _KSplitLoss.apply(flat(f_real_l), flat(f_fake_l), feat(h_fake_l), feat(h_real_l), feat(m_real_l),
+                                 feat(m_fake_l), float(scaling_coef), float(epsilon), int(L), group).reshape(())
     return _ShardedLoss.apply(flat(f_real_l), flat(f_fake_l), feat(h_fake_l), feat(h_real_l), feat(m_real_l),
                               feat(m_fake_l), float(scaling_coef), float(epsilon), int(L), group, ops).reshape(())
 

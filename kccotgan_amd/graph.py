@@ -190,3 +190,120 @@ class GraphedShardedStep:
                 self._gather(self._C3g, self._blk_t)
                 self.graph_b.replay()
         return self.loss, self.grads
+
+
+class GraphedKSplitStep:
+    """Forward + backward of the contraction-sharded protocol (``dist._KSplitLoss``) at dLoss = 1 for one rank:
+    all-to-all x2 + all-gather (features) -> graph A (fp64 Gram sums of the rank's K-slice) -> all-reduce(SUM) of the
+    sums -> graph B (finalize, solves, reverse sweep, video gradient of ALL samples on the slice, feature gradients
+    of the rank's samples) -> all-to-all back.  Same calls and order as the eager Function: bit-identical results."""
+
+    def __init__(self, shard, scaling_coef, group=None, epsilon=1.0, L=100, warmup=2):
+        import ctypes
+        import torch.distributed as dist
+        from . import dist as kd
+        from . import _lib
+        from ._lib import lib, check
+        self._kd, self._dist, self.group = kd, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        Bl = shard["real"].shape[0]
+        dev = shard["real"].device
+        flat = lambda v: v.detach().reshape(Bl, -1).float().contiguous().clone()
+        self.local = {"real": flat(shard["real"]), "fake": flat(shard["fake"]),
+                      "feats": torch.stack([shard[k].detach().float() for k in _FEATS], dim=1).contiguous()}
+        self._shapes = {k: tuple(shard[k].shape) for k in ("fake",) + _FEATS}
+        B, K = Bl * self.world, self.local["real"].shape[1]
+        if not kd.ksplit_supported(B, K, self.world):
+            raise NotImplementedError("ksplit protocol: unsupported shape B=%d K=%d on %d ranks" % (B, K, self.world))
+        Ks = K // self.world
+        T, J = self.local["feats"].shape[2], self.local["feats"].shape[3]
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        self._f = [new(B, T, J) for _ in range(4)]
+        self._C3 = new(3, B, B)
+        self._dfake_s = new(B, Ks)
+        self._fg = [new(Bl, T, J) for _ in range(4)]
+        self._one = torch.ones((), device=dev)
+        self._wsb = int(lib.kccot_pairwise_cost3_workspace_bytes(B, Ks))
+        self._ws = torch.empty(self._wsb, dtype=torch.uint8, device=dev)
+        off, cnt = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        check(lib.kccot_pairwise_cost3_gram_sums_span(B, Ks, ctypes.byref(off), ctypes.byref(cnt)), "gram_sums_span")
+        self._gsum = self._ws[off.value:off.value + 8 * cnt.value].view(torch.float64)
+        self._cfg = (float(scaling_coef), float(epsilon), int(L), self.rank * Bl, Bl, B, Ks, T, J)
+        self._exchange_in()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._exchange_in()
+                self._seg_a()
+                kd._all_reduce_sum(self._gsum, group)
+                self._seg_b()
+                kd.all_to_all_rows(self._dfake_s, group)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
+            self._seg_a()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
+            self.loss, nits = self._seg_b()
+        self.nits, self.nits_executed = nits[:3], nits[3:]
+        self.grads = None
+
+    def _exchange_in(self):
+        kd = self._kd
+        rs, fs = kd.all_to_all_slices(self.local["real"], self.group), kd.all_to_all_slices(self.local["fake"], self.group)
+        ft = kd.all_gather_cat(self.local["feats"], self.group)
+        if not hasattr(self, "_real_s"):
+            self._real_s, self._fake_s, self._feats = rs.clone(), fs.clone(), ft.clone()       # static homes
+        else:
+            self._real_s.copy_(rs); self._fake_s.copy_(fs); self._feats.copy_(ft)
+
+    def _cost3(self, flags):
+        from . import _lib
+        from ._lib import lib, check, ptr, stream_of
+        sc, _, _, _, _, B, Ks, T, J = self._cfg
+        check(lib.kccot_pairwise_cost3_f32(ptr(self._real_s), ptr(self._fake_s), B, Ks, sc, ptr(self._f[0]), ptr(self._f[1]),
+                                           ptr(self._f[2]), ptr(self._f[3]), T, J, flags, ptr(self._C3), self._ws.data_ptr(),
+                                           self._wsb, stream_of(self._real_s)), "pairwise_cost3")
+
+    def _seg_a(self):
+        from . import _lib
+        for i in range(4):
+            self._f[i].copy_(self._feats[:, i])
+        self._cost3(_lib.COST_GRAM_SUMS_ONLY)
+
+    def _seg_b(self):
+        from . import _lib
+        from ._lib import lib, check, ptr, stream_of, workspace
+        sc, eps, L, row_begin, Bl, B, Ks, T, J = self._cfg
+        H = self._kd.HipOps
+        self._cost3(_lib.COST_FROM_GRAM_SUMS)
+        loss, saved = H.divergence_fwd(self._C3, eps, L)
+        dC3 = H.divergence_bwd(saved, self._one)
+        ws, wsb = workspace(lib.kccot_pairwise_cost3_bwd_workspace_bytes(B, Ks), self._real_s)
+        check(lib.kccot_pairwise_cost3_bwd_f32(ptr(dC3), ptr(self._real_s), ptr(self._fake_s), B, Ks, sc, None, None, None, None,
+                                               1, 1, ptr(self._dfake_s), None, None, None, None, ws, wsb,
+                                               stream_of(self._real_s)), "pairwise_cost3_bwd")
+        check(lib.kccot_pairwise_cost3_bwd_rows_f32(ptr(dC3), ptr(self._real_s), ptr(self._fake_s), B, Ks, sc, ptr(self._f[0]),
+                                                    ptr(self._f[1]), ptr(self._f[2]), ptr(self._f[3]), T, J, row_begin, Bl, None,
+                                                    ptr(self._fg[0]), ptr(self._fg[1]), ptr(self._fg[2]), ptr(self._fg[3]),
+                                                    None, 0, stream_of(self._real_s)), "pairwise_cost3_bwd_rows")
+        return loss, saved[3]
+
+    def __call__(self, **inputs):
+        with torch.no_grad():
+            for k, v in inputs.items():
+                if k in ("real", "fake"):
+                    self.local[k].copy_(v.reshape(self.local[k].shape))
+                else:
+                    self.local["feats"][:, _FEATS.index(k)].copy_(v)
+            self._exchange_in()
+            self.graph_a.replay()
+            self._kd._all_reduce_sum(self._gsum, self.group)
+            self.graph_b.replay()
+            dfake = self._kd.all_to_all_rows(self._dfake_s, self.group)
+        self.grads = {"fake": dfake.reshape(self._shapes["fake"])}
+        for k, v in zip(_FEATS, self._fg):
+            self.grads[k] = v.reshape(self._shapes[k])
+        return self.loss, self.grads

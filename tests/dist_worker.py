@@ -65,9 +65,10 @@ def run(rank, world, port, shape, seed, regime, device, use_hip, out_path):
     res = {"loss": np.array(float(loss))}
     for k, g in zip(names, grads):
         res["d" + k] = g.detach().cpu().double().numpy()
-    if use_hip:      # the graph-captured form of the same step (kccotgan_amd.graph.GraphedShardedStep): bit-identical
-        from kccotgan_amd.graph import GraphedShardedStep
-        step = GraphedShardedStep(shard, cases.SC, L=100)
+    if use_hip:      # the graph-captured form of the same step (kccotgan_amd.graph): bit-identical
+        from kccotgan_amd.graph import GraphedShardedStep, GraphedKSplitStep
+        cls = GraphedKSplitStep if os.environ.get("KCCOT_DIST_PROTOCOL") == "ksplit" else GraphedShardedStep
+        step = cls(shard, cases.SC, L=100)
         for _ in range(2):
             gl, gg = step()
         res["graphed_loss_equal"] = np.array(bool(torch.equal(gl.reshape(()), loss.detach().reshape(()))))

@@ -66,15 +66,16 @@ def test_sharded_equals_single_process_oracle(world, shape, seed, regime, tmp_pa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("protocol", ["replicated", "row_blocks"])
+@pytest.mark.parametrize("protocol", ["replicated", "row_blocks", "ksplit"])
 @pytest.mark.parametrize("shape,seed,regime", [("deci64", 0, "near"), ("cfg1", 1, "far")])
 def test_sharded_hip_equals_single_gpu(shape, seed, regime, protocol, tmp_path):
     """Two ranks (gloo, one GPU) against the single-GPU loss.  `replicated`: batches of at most 64 assemble the whole
     cost matrices on every rank (HipOps.replicate_costs; cfg1's K = 24 576 qualifies, so does deci64);
-    `row_blocks`: the protocol of larger batches (row blocks on the direct kernel + all-gather), forced."""
+    `row_blocks`: the protocol of larger batches (row blocks on the direct kernel + all-gather), forced;
+    `ksplit`: the contraction-sharded protocol (all-to-all into K-slices, all-reduced fp64 Gram sums, all-to-all back)."""
     from kccotgan_amd import gan_utils as G
     res = launch(2, shape, seed, regime, "cuda:0", "hip", tmp_path,
-                 env={"KCCOT_DIST_ROW_BLOCKS": "1"} if protocol == "row_blocks" else None)
+                 env={"row_blocks": {"KCCOT_DIST_ROW_BLOCKS": "1"}, "ksplit": {"KCCOT_DIST_PROTOCOL": "ksplit"}}.get(protocol))
     inp = cases.gen_inputs(shape, seed, regime)
     t = {k: torch.from_numpy(v).to("cuda:0") for k, v in inp.items()}
     for k in NAMES:

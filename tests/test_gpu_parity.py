@@ -369,6 +369,53 @@ def test_cost3_blocked_mfma_path_above_64(G, L, B, regime):
         np.testing.assert_allclose(np.diag(blocked[k]), np.diag(ref), rtol=2e-5, atol=1e-7, err_msg=tag + " diagonal")
 
 
+@pytest.mark.parametrize("B", [48, 64, 128])
+def test_cost3_gram_sums_split_equals_one_call(L, B):
+    """KCCOT_COST_GRAM_SUMS_ONLY + KCCOT_COST_FROM_GRAM_SUMS (the contraction-sharded caller's two calls, here without
+    the all-reduce in between) give the bits of the one-shot call; and summing the Gram sums of two K-halves before
+    the finalize step gives the full-K result to rounding (what two ranks do)."""
+    import ctypes
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, ptr, check
+    rng = np.random.default_rng(500 + B)
+    K, T, J = 2048, 6, 4
+    real = torch.from_numpy(rng.random((B, K), dtype=np.float32)).to(DEV)
+    fake = (real + 0.02 * torch.randn(B, K, device=DEV)).clamp_(0, 1).contiguous()
+    f = [torch.from_numpy(rng.random((B, T, J), dtype=np.float32)).to(DEV) for _ in range(4)]
+
+    def call(x, y, k, flags, C3, ws):
+        check(lib.kccot_pairwise_cost3_f32(ptr(x), ptr(y), B, k, cases.SC, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), T, J,
+                                           flags, ptr(C3), ws.data_ptr(), ws.numel(), None), "pairwise_cost3")
+
+    def span(k):
+        off, cnt = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        check(lib.kccot_pairwise_cost3_gram_sums_span(B, k, ctypes.byref(off), ctypes.byref(cnt)), "span")
+        return off.value, cnt.value
+
+    ws = torch.empty(int(lib.kccot_pairwise_cost3_workspace_bytes(B, K)), dtype=torch.uint8, device=DEV)
+    one, two = torch.empty(3, B, B, device=DEV), torch.empty(3, B, B, device=DEV)
+    call(real, fake, K, 0, one, ws)
+    call(real, fake, K, _lib.COST_GRAM_SUMS_ONLY, two, ws)
+    call(real, fake, K, _lib.COST_FROM_GRAM_SUMS, two, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)
+    # two K-halves, summed like an all-reduce would
+    Kh = K // 2
+    off, cnt = span(Kh)
+    assert cnt > 0
+    halves = [real[:, :Kh].contiguous(), real[:, Kh:].contiguous()], [fake[:, :Kh].contiguous(), fake[:, Kh:].contiguous()]
+    wsh = [torch.empty(int(lib.kccot_pairwise_cost3_workspace_bytes(B, Kh)), dtype=torch.uint8, device=DEV) for _ in range(2)]
+    out = torch.empty(3, B, B, device=DEV)
+    for r in range(2):
+        call(halves[0][r], halves[1][r], Kh, _lib.COST_GRAM_SUMS_ONLY, out, wsh[r])
+    g0 = wsh[0][off:off + 8 * cnt].view(torch.float64)
+    g0 += wsh[1][off:off + 8 * cnt].view(torch.float64)
+    call(halves[0][0], halves[1][0], Kh, _lib.COST_FROM_GRAM_SUMS, out, wsh[0])
+    torch.cuda.synchronize()
+    ref = one.cpu().numpy()
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-6 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("B", [128, 256])
 def test_loss_at_larger_batches(G, B):
     """configs 3/4 batch sizes (decimated frames so that the CPU oracle finishes in seconds): direct

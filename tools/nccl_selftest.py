@@ -45,5 +45,22 @@ for _ in range(100):
     gs()
 torch.cuda.synchronize()
 print("graphed sharded step (world 1, nccl calls in place): %.1f us/step" % ((time.perf_counter() - t0) / 100 * 1e6))
+# the contraction-sharded protocol: all_to_all_single / all_reduce(SUM, fp64) in place of the all-gathers
+from kccotgan_amd.graph import GraphedKSplitStep
+lk = kd.sharded_sinkhorn_loss(shard["real"], shard["fake"], bench.SC, shard["h_fake"], shard["m_real"], shard["h_real"],
+                              shard["m_fake"], protocol="ksplit")
+gk = torch.autograd.grad(lk, [shard[k] for k in ("fake", "h_fake", "h_real", "m_real", "m_fake")])
+ks = GraphedKSplitStep(shard, bench.SC)
+for _ in range(3):
+    kl, kg = ks()
+torch.cuda.synchronize()
+assert torch.equal(kl.reshape(()), lk.detach().reshape(())), (float(kl), float(lk))
+assert all(torch.equal(kg[k], g) for k, g in zip(("fake", "h_fake", "h_real", "m_real", "m_fake"), gk))
+assert abs(float(lk) - float(loss)) <= 2e-6 * abs(float(loss))
+t0 = time.perf_counter()
+for _ in range(100):
+    ks()
+torch.cuda.synchronize()
+print("graphed ksplit step (world 1, nccl calls in place): %.1f us/step" % ((time.perf_counter() - t0) / 100 * 1e6))
 print("nccl selftest ok: backend=%s loss=%.6f" % (dist.get_backend(), float(loss)))
 dist.destroy_process_group()
