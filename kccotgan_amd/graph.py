@@ -154,6 +154,19 @@ class GraphedShardedStep:
             out.copy_(self._kd.all_gather_cat(local, self.group))
 
     def _gather_inputs(self):
+        # RCCL: the three all-gathers as ONE coalesced group (one launch, one set of fixed latencies); decided at the
+        # first call, sequential calls if this torch build has no coalesced all-gather
+        if self._nccl and getattr(self, "_coalesce", True):
+            try:
+                with self._dist._coalescing_manager(group=self.group):
+                    for k in ("real", "fake", "feats"):
+                        self._dist.all_gather_into_tensor(self.full[k], self.local[k], group=self.group)
+                self._coalesce = True
+                return
+            except Exception:
+                if getattr(self, "_coalesce", None) is True:
+                    raise                                   # it worked before: a real failure
+                self._coalesce = False
         for k in ("real", "fake", "feats"):
             self._gather(self.full[k], self.local[k])
 
