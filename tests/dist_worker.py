@@ -67,7 +67,12 @@ def run(rank, world, port, shape, seed, regime, device, use_hip, out_path):
         res["d" + k] = g.detach().cpu().double().numpy()
     if use_hip:      # the graph-captured form of the same step (kccotgan_amd.graph): bit-identical
         from kccotgan_amd.graph import GraphedShardedStep, GraphedKSplitStep
-        cls = GraphedKSplitStep if os.environ.get("KCCOT_DIST_PROTOCOL") == "ksplit" else GraphedShardedStep
+        from kccotgan_amd import dist as _kd
+        B_, K_ = inp["real"].shape[0], int(np.prod(inp["real"].shape[1:]))
+        proto = os.environ.get("KCCOT_DIST_PROTOCOL", "auto")
+        if proto == "auto":
+            proto = "ksplit" if (B_ > 64 and _kd.ksplit_supported(B_, K_, world)) else "gather"
+        cls = GraphedKSplitStep if proto == "ksplit" else GraphedShardedStep
         step = cls(shard, cases.SC, L=100)
         for _ in range(2):
             gl, gg = step()

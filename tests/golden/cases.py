@@ -20,6 +20,7 @@ SHAPES = {
     "deci64": (64, 8, 30, 8, 1, 8),     # config-2 batch/time, decimated frame (D = 64)
     "cfg1": (8, 64, 20, 64, 1, 8),      # BASELINE configs[0]
     "cfg2": (64, 64, 30, 64, 1, 8),     # BASELINE configs[1]
+    "deci128": (128, 8, 10, 8, 4, 8),   # config-3 batch, decimated frames (K = 2560): multi-rank tests only, no golden file
 }
 
 # (shape name, seed, regime)
