@@ -135,3 +135,154 @@ class _Math:
 
 
 math = _Math()
+
+
+# --------------------------------------------------------------------------------------------
+# Round 2: the primitives ``/root/reference/data_utils.py`` needs so that ``KernelSmoothing``
+# (:478-586), ``WarmUp`` (:589-621) and ``exponential_decay_with_warmup`` (:624-633) can be run
+# verbatim by tests/golden/make_golden_smoothing.py.  The convolutions are torch's CPU kernels
+# (``torch.nn.functional.conv1d/2d/3d``, cross-correlation like TF's) -- an implementation that
+# shares nothing with oracle/smoothing_np.py or the HIP kernels.
+# --------------------------------------------------------------------------------------------
+def _range_with_dtype(*args, **kwargs):
+    dtype = kwargs.pop("dtype", None)
+    out = _np.arange(*args)
+    return out if dtype is None else out.astype(dtype)
+
+
+range = _range_with_dtype  # noqa: A001 - gan_utils.py calls tf.range(L) (integers, no dtype)
+
+
+def constant(value, dtype=None):
+    return _np.asarray(value, dtype=dtype)
+
+
+def pad(tensor, paddings, mode="CONSTANT"):
+    """tf.pad: REFLECT mirrors without repeating the edge sample (NumPy 'reflect'); SYMMETRIC
+    repeats it (NumPy 'symmetric')."""
+    mode = {"CONSTANT": "constant", "REFLECT": "reflect", "SYMMETRIC": "symmetric"}[mode.upper()]
+    widths = [tuple(int(v) for v in p) for p in _np.asarray(paddings)]
+    return _np.pad(_np.asarray(tensor), widths, mode=mode)
+
+
+def meshgrid(*args, indexing="xy"):
+    return _np.meshgrid(*args, indexing=indexing)
+
+
+def concat(values, axis):
+    return _np.concatenate([_np.asarray(v) for v in values], axis=axis)
+
+
+def _conv_nd(nd, inputs, filters, padding):
+    """channels-last input [N, *spatial, Cin], filter [*k, Cin, Cout], stride 1 -> torch conv."""
+    import torch
+    import torch.nn.functional as F
+    if padding != "VALID":
+        raise NotImplementedError("stand-in implements VALID only (all the reference uses)")
+    x = _np.asarray(inputs)
+    w = _np.asarray(filters).astype(x.dtype)
+    perm_in = (0, nd + 1) + tuple(_np.arange(1, nd + 1))          # -> [N, Cin, *spatial]
+    perm_w = (nd + 1, nd) + tuple(_np.arange(0, nd))              # -> [Cout, Cin, *k]
+    xt = torch.from_numpy(_np.ascontiguousarray(_np.transpose(x, perm_in)))
+    wt = torch.from_numpy(_np.ascontiguousarray(_np.transpose(w, perm_w)))
+    out = (F.conv1d, F.conv2d, F.conv3d)[nd - 1](xt, wt)
+    perm_out = (0,) + tuple(_np.arange(2, nd + 2)) + (1,)         # -> [N, *spatial, Cout]
+    return _np.ascontiguousarray(out.permute(*[int(p) for p in perm_out]).numpy())
+
+
+class _NN:
+    @staticmethod
+    def conv1d(input, filters, stride=1, padding="VALID"):       # noqa: A002
+        assert stride in (1, [1], [1, 1, 1])
+        return _conv_nd(1, input, filters, padding)
+
+    @staticmethod
+    def conv2d(input, filters, strides=1, padding="VALID"):      # noqa: A002
+        assert strides in (1, [1, 1], [1, 1, 1, 1])
+        return _conv_nd(2, input, filters, padding)
+
+    @staticmethod
+    def conv3d(input, filters, strides=1, padding="VALID"):      # noqa: A002
+        assert strides in (1, [1, 1, 1], [1, 1, 1, 1, 1])
+        return _conv_nd(3, input, filters, padding)
+
+
+nn = _NN()
+nest = object()          # data_utils.py:26,270 only binds the name
+
+
+class _NameScope:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        return self.name
+
+    def __exit__(self, *exc):
+        return False
+
+
+def name_scope(name):
+    return _NameScope(name)
+
+
+def cond(pred, true_fn, false_fn, name=None):
+    return true_fn() if bool(pred) else false_fn()
+
+
+def _pow(x, y):
+    return _np.power(x, y)
+
+
+_Math.pow = staticmethod(_pow)
+
+
+class _Schedules:
+    class LearningRateSchedule:
+        def __init__(self):
+            pass
+
+    class ExponentialDecay(LearningRateSchedule):
+        """Keras' documented rule: lr * rate ** (step / decay_steps), the exponent floored when
+        staircase=True (kernel_train.py:57-58 builds it that way).  A stand-in for Keras, NOT
+        reference code: only what WarmUp does with it is pinned."""
+
+        def __init__(self, initial_learning_rate, decay_steps, decay_rate, staircase=False, name=None):
+            self.initial_learning_rate = initial_learning_rate
+            self.decay_steps = decay_steps
+            self.decay_rate = decay_rate
+            self.staircase = staircase
+
+        def __call__(self, step):
+            p = _np.asarray(step, dtype=float32) / float32(self.decay_steps)
+            if self.staircase:
+                p = _np.floor(p)
+            return float32(self.initial_learning_rate) * _np.power(float32(self.decay_rate), p)
+
+
+class _Optimizers:
+    schedules = _Schedules
+
+
+class _Keras:
+    optimizers = _Optimizers
+
+
+keras = _Keras
+
+
+class _V1Train:
+    @staticmethod
+    def exponential_decay(learning_rate, global_step, decay_steps, decay_rate, staircase=False, name=None):
+        return _Schedules.ExponentialDecay(learning_rate, decay_steps, decay_rate, staircase)(global_step)
+
+
+class _V1:
+    train = _V1Train
+
+
+class _Compat:
+    v1 = _V1
+
+
+compat = _Compat

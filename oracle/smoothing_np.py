@@ -1,10 +1,14 @@
 """CPU oracle for KernelSmoothing (reference data_utils.py:478-586), NumPy.
 
-TEST INFRASTRUCTURE ONLY.  ``data_utils.py`` cannot be imported here (it needs tensorflow, cv2,
-absl, IPython at module level) and the reference holds no fixture for it, so against real
-TensorFlow this restatement is PARITY UNPINNED; it is pinned by the known-answer tests in
-tests/test_oracle_smoothing.py (taps sum to 1, constant video -> ones, REFLECT = numpy 'reflect',
-dense 7x7x7 == separable, cross-check with scipy.ndimage 'mirror').
+TEST INFRASTRUCTURE ONLY.  PINNED (round 2): tests/golden/smooth_*.npz hold the outputs of the
+reference's own ``data_utils.KernelSmoothing`` -- the file imported verbatim from /root/reference by
+tests/golden/make_golden_smoothing.py over ``oracle/refshim`` (TensorFlow is not installed; the
+stand-in supplies tf.pad/transpose/reshape/... in NumPy and tf.nn.conv1d/conv3d as torch CPU
+convolutions) -- for C = 1 and C = 3 (both code branches), sigma 5.0 / 2.0 / 1.3, radius 3 and 4,
+small shapes plus the configs[0] frame size and T = 30.  tests/test_smoothing_golden.py checks
+this restatement against them (fp32: 1e-6 temporal / 4e-6 conv3d absolute on outputs in [0,1];
+fp64: 1e-13), the known-answer tests in tests/test_oracle_smoothing.py stay as a second net.
+What is not pinned: TensorFlow/Eigen's own summation order (as for the loss path).
 
 The dense functions follow the reference literally (pad, then a VALID correlation with the full
 kernel); the ``*_separable`` ones are the algebraically identical form the HIP kernels use.

@@ -491,7 +491,7 @@ def test_very_near_regime_keeps_relative_accuracy(G, L):
 
 
 # ---------------------------------------------------------------- properties at full size (configs[1])
-def test_full_size_properties(G, L):
+def test_cfg2_fixture_properties(G, L):
     g, inp, t = load("cfg2", 0, "near")
     B = t["real"].shape[0]
     args = lambda r, f, hf, mr, hr, mf: (r, f, cases.SC, 0.8, 100, hf, mr, hr, mf)
