@@ -25,19 +25,17 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-# MIOpen's `ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC` solver (kernel `igemm_bwd_gtcx35_nhwc_fp32_*`) reads past the
-# end of a buffer in the backward of these models on this ROCm image: "Memory access fault by GPU" on a 2 MB segment
-# boundary whenever the caching allocator happens to place the overrun buffer at the end of a segment (found with
-# AMD_LOG_LEVEL=3 + blocking launches; a pure-PyTorch loop reproduces it).  With that one solver
-# switched off MIOpen picks another backward-data kernel and every run has been clean, at 0.93 s per full-size
-# training iteration (0.76 s with the faulting solver, 6.6 s on the native ATen kernels).  The switch is an
-# environment variable MIOpen reads when it selects solvers, so it is set here, at import, unless the user set it.
-os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
+# The MIOpen solver switch that keeps these models' backward off the faulting `igemm_bwd_gtcx35_nhwc_fp32_*` kernel is
+# set by the package's __init__ (it must precede the first convolution of the process).  Where that cannot be
+# guaranteed -- the variable was set to something else by the user, or the GPU was already in use when the package
+# was imported -- the default falls back to the conservative mode below (no MIOpen kernel at all).
+from . import MIOPEN_SWITCH, MIOPEN_WORKAROUND_GUARANTEED
 
 # Layer families listed in KCCOT_NATIVE_CONV (comma separated: convlstm, deconv, dconv) run on the native ATen
 # convolution kernels instead of MIOpen's (the conservative mode: no MIOpen kernel at all when all three are listed;
-# the forward contexts below cover the forward calls, `conv_guard` the backward).  Default: none.
-_NATIVE_DEFAULT = ""
+# the forward contexts below cover the forward calls, `conv_guard` the backward).  Default: none when the MIOpen
+# workaround is in effect, all three otherwise.
+_NATIVE_DEFAULT = "" if MIOPEN_WORKAROUND_GUARANTEED else "convlstm,deconv,dconv"
 _NATIVE = set(filter(None, os.environ.get("KCCOT_NATIVE_CONV", _NATIVE_DEFAULT).split(",")))
 
 

@@ -31,10 +31,56 @@ from .data_utils import KernelSmoothing
 
 
 def warmup_exponential_decay(step, base_lr, warmup_steps=10000, decay_steps=5000, decay_rate=0.975):
-    """data_utils.py:589-621 WarmUp around kernel_train.py:57 ExponentialDecay(staircase=True)."""
+    """data_utils.py:589-621 WarmUp around kernel_train.py:57 ExponentialDecay(staircase=True).  Pinned against the
+    reference's own WarmUp class (tests/golden/lr_schedule.npz, tests/test_smoothing_golden.py)."""
     if step < warmup_steps:
         return base_lr * (step / warmup_steps)
     return base_lr * decay_rate ** ((step - warmup_steps) // decay_steps)
+
+
+class KerasSharedAdam:
+    """``tf.keras.optimizers.Adam(schedule, beta_1=0.5, beta_2=0.9)`` as the reference uses it: ONE optimiser
+    object per step kind whose ``apply_gradients`` is called TWICE per training step, once per network
+    (kernel_train.py:62-63,254-255,290-291).  Keras semantics reproduced:
+
+    * ``iterations`` counts ``apply_gradients`` calls, so it advances by 2 per training step;
+    * the schedule is evaluated at the PRE-increment count (the very first update runs at lr(0) = 0 under WarmUp),
+      the first network of a step sees lr(2k), the second lr(2k+1);
+    * the bias correction uses t = iterations + 1 for every variable of that call, although each variable's moments
+      have only been updated k+1 times;
+    * update rule ``var -= lr_t * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + epsilon)``, epsilon = 1e-7 outside
+      the bias correction (Keras' "epsilon hat").
+    """
+
+    def __init__(self, schedule, beta_1=0.5, beta_2=0.9, epsilon=1e-7):
+        self.schedule, self.beta_1, self.beta_2, self.epsilon = schedule, beta_1, beta_2, epsilon
+        self.iterations = 0
+        self.state = {}
+        self.last_lr = None
+
+    @torch.no_grad()
+    def apply_gradients(self, grads_and_vars):
+        pairs = [(g, p) for g, p in grads_and_vars if g is not None]
+        t = self.iterations + 1
+        lr_t = float(self.schedule(self.iterations))
+        self.last_lr = lr_t
+        alpha = lr_t * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        if pairs:
+            ps = [p for _, p in pairs]
+            gs = [g for g, _ in pairs]
+            for p in ps:
+                if p not in self.state:
+                    self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
+            ms = [self.state[p][0] for p in ps]
+            vs = [self.state[p][1] for p in ps]
+            torch._foreach_mul_(ms, self.beta_1)
+            torch._foreach_add_(ms, gs, alpha=1.0 - self.beta_1)
+            torch._foreach_mul_(vs, self.beta_2)
+            torch._foreach_addcmul_(vs, gs, gs, value=1.0 - self.beta_2)
+            denom = torch._foreach_sqrt(vs)
+            torch._foreach_add_(denom, self.epsilon)
+            torch._foreach_addcdiv_(ps, ms, denom, value=-alpha)
+        self.iterations += 1
 
 
 class KCCOTTrainer:
@@ -65,15 +111,21 @@ class KCCOTTrainer:
                                                       filter_size=d_filter_size, **mk).to(self.device)
         self.discriminator_m = gan.VideoDiscriminator(batch_size, total_time_steps, d_state_size, x_width, x_height,
                                                       filter_size=d_filter_size, **mk).to(self.device)
-        self.g_params = list(self.context_encoder.parameters()) + list(self.decoder.parameters())
-        self.d_params = list(self.discriminator_h.parameters()) + list(self.discriminator_m.parameters())
-        self.gen_optimiser = torch.optim.Adam(self.g_params, lr=lr, betas=(0.5, 0.9), eps=1e-7)
-        self.dischm_optimiser = torch.optim.Adam(self.d_params, lr=lr, betas=(0.5, 0.9), eps=1e-7)
+        # (first network, second network) of each shared optimiser, in the reference's apply order (:254-255,290-291)
+        self.g_nets = (list(self.context_encoder.parameters()), list(self.decoder.parameters()))
+        self.d_nets = (list(self.discriminator_h.parameters()), list(self.discriminator_m.parameters()))
+        self.g_params = self.g_nets[0] + self.g_nets[1]
+        self.d_params = self.d_nets[0] + self.d_nets[1]
         self.base_lr, self.warmup = lr, warmup
-        self.g_steps = self.d_steps = 0
-        if group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        schedule = lambda it: warmup_exponential_decay(it, lr, warmup)           # :54-59
+        self.gen_optimiser = KerasSharedAdam(schedule, beta_1=0.5, beta_2=0.9)    # :62
+        self.dischm_optimiser = KerasSharedAdam(schedule, beta_1=0.5, beta_2=0.9)  # :63
+        if data_parallel:
             for p in self.g_params + self.d_params:                              # identical replicas
                 dist.broadcast(p.data, src=0, group=group)
+            # ... but independent generator noise: every rank has consumed the RNG identically up to here, so
+            # without this each shard of the global batch would be generated from the same z
+            torch.manual_seed(seed + 1000 * (1 + dist.get_rank(group)))
 
     # ------------------------------------------------------------------ the shared forward
     def _forward(self, real_in, real_pred, sigma, generator_grad=True):
@@ -110,19 +162,24 @@ class KCCOTTrainer:
     def _world(self):
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
 
-    def _apply(self, optimiser, params, step):
+    def _apply(self, optimiser, nets, grads):
+        """``optimiser.apply_gradients`` once per network, first then second (kernel_train.py:254-255 / :290-291);
+        data-parallel: the loss is replicated and every rank holds the partial derivative through its own samples,
+        so the gradients are all-reduced with SUM first (one flat buffer)."""
+        grads = list(grads)
+        params = nets[0] + nets[1]
         if self._world() > 1:
-            flat = torch.cat([p.grad.reshape(-1) if p.grad is not None else p.new_zeros(p.numel()) for p in params])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)         # replicated loss, partial grads
+            flat = torch.cat([g.reshape(-1) if g is not None else p.new_zeros(p.numel()) for g, p in zip(grads, params)])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             off = 0
-            for p in params:
+            for i, p in enumerate(params):
                 n = p.numel()
-                if p.grad is not None:
-                    p.grad.copy_(flat[off:off + n].view_as(p))
+                if grads[i] is not None:
+                    grads[i] = flat[off:off + n].view_as(p)
                 off += n
-        for g in optimiser.param_groups:
-            g["lr"] = warmup_exponential_decay(step, self.base_lr, self.warmup)
-        optimiser.step()
+        n0 = len(nets[0])
+        optimiser.apply_gradients(zip(grads[:n0], nets[0]))
+        optimiser.apply_gradients(zip(grads[n0:], nets[1]))
 
     # ------------------------------------------------------------------ kernel_train.py:219-256
     def disc_training_step(self, real_in, real_pred, sigma):
@@ -134,29 +191,21 @@ class KCCOTTrainer:
             return self._gen_training_step(real_in, real_pred, sigma)
 
     def _disc_training_step(self, real_in, real_pred, sigma):
-        self.dischm_optimiser.zero_grad(set_to_none=True)
         loss, m_real = self._forward(real_in, real_pred, sigma, generator_grad=False)
         if self._world() > 1:               # pM couples the whole batch (std and mean over b): use the global M
             from . import dist as kd
             m_real = kd.all_gather_local_grad(m_real, self.group)
         pm1 = gan_utils.scale_invariante_martingale_regularization(m_real, self.reg_penalty, self.scaling_coef)   # :249
         disc_loss = -loss + pm1                                                  # :250
-        grads = torch.autograd.grad(disc_loss, self.d_params, allow_unused=True)
-        for p, g in zip(self.d_params, grads):
-            p.grad = g
-        self.d_steps += 1
-        self._apply(self.dischm_optimiser, self.d_params, self.d_steps)          # :252-255
+        grads = torch.autograd.grad(disc_loss, self.d_params, allow_unused=True)  # :252
+        self._apply(self.dischm_optimiser, self.d_nets, grads)                   # :254-255
         return pm1.detach()                                                      # :256
 
     # ------------------------------------------------------------------ kernel_train.py:259-292
     def _gen_training_step(self, real_in, real_pred, sigma):
-        self.gen_optimiser.zero_grad(set_to_none=True)
         loss, _ = self._forward(real_in, real_pred, sigma)
         grads = torch.autograd.grad(loss, self.g_params, allow_unused=True)      # :289
-        for p, g in zip(self.g_params, grads):
-            p.grad = g
-        self.g_steps += 1
-        self._apply(self.gen_optimiser, self.g_params, self.g_steps)             # :290-291
+        self._apply(self.gen_optimiser, self.g_nets, grads)                      # :290-291
         return loss.detach()                                                     # :292
 
     # ------------------------------------------------------------------ kernel_train.py:338-355

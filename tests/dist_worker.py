@@ -134,9 +134,25 @@ def run_train(rank, world, port, seed, device, out_path):
     dist.destroy_process_group()
 
 
+def run_noise(rank, world, port, device, out_path):
+    """Data-parallel trainer built with the DEFAULT seed on every rank: identical weights, different generator noise."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kccotgan_amd.kernel_train import KCCOTTrainer
+    tr = KCCOTTrainer(2, total_time_steps=4, int_time_steps=2, x_height=16, x_width=16, channels=1, g_state_size=2,
+                      d_state_size=2, g_filter_size=2, d_filter_size=2, z_channels=3, kernel="none", device=device)
+    z = torch.randn(tr.z_shape, device=device)           # what _forward draws (kernel_train.py:220,260)
+    p = torch.cat([q.detach().reshape(-1) for q in tr.g_params + tr.d_params])
+    np.savez(out_path % rank, z=z.cpu().numpy(), p=p.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     a = sys.argv
-    if a[8] == "train":
+    if a[8] == "noise":
+        run_noise(int(a[1]), int(a[2]), int(a[3]), a[7], a[9])
+    elif a[8] == "train":
         run_train(int(a[1]), int(a[2]), int(a[3]), int(a[5]), a[7], a[9])
     elif a[8] == "smooth":
         run_smooth(int(a[1]), int(a[2]), int(a[3]), int(a[5]), a[7], a[9])

@@ -54,9 +54,34 @@ def counted(tf, fn, *a, **k):
     return val, (tf.lse_calls - before) // 2
 
 
+def memoise_cost_xy(gu):
+    """configs[1] full size: every reference call below re-builds the [B,B,T,D] broadcast of
+    gan_utils.py:14-16 (2 GB fp32 / 4 GB fp64, ~10 s).  The reference functions look ``cost_xy`` up as a
+    module global, so wrapping it with a cache keyed on the argument OBJECTS lets compute_sinkhorn /
+    bi_causal_modified_cost / benchmark_sinkhorn run verbatim while the reference's own cost_xy result for
+    (x, y) is built once.  Nothing but the repeated evaluation is skipped."""
+    orig, cache = gu.cost_xy, {}
+
+    def cost_xy(x, y, scaling_coef):
+        key = (id(x), id(y), float(scaling_coef))
+        if key not in cache:
+            cache[key] = (orig(x, y, scaling_coef), x, y)       # keep x, y alive so the ids stay unique
+        return cache[key][0]
+    gu.cost_xy = cost_xy
+    return lambda: setattr(gu, "cost_xy", orig)
+
+
 def run_case(tf, gu, shape, seed, regime, dtype, heavy):
     sfx = "" if dtype == np.float32 else "_f64"
     tf.set_float(dtype)
+    restore = memoise_cost_xy(gu) if heavy else (lambda: None)
+    try:
+        return _run_case(tf, gu, shape, seed, regime, dtype, sfx)
+    finally:
+        restore()
+
+
+def _run_case(tf, gu, shape, seed, regime, dtype, sfx):
     inp = cases.gen_inputs(shape, seed, regime)
     real, fake = inp["real"].astype(dtype), inp["fake"].astype(dtype)
     hf, mr, hr, mf = (inp[k].astype(dtype) for k in ("h_fake", "m_real", "h_real", "m_fake"))
@@ -74,23 +99,23 @@ def run_case(tf, gu, shape, seed, regime, dtype, heavy):
         out["nits_" + tag] = n
         out["C_" + tag] = gu.modified_cost(a, b, h, m, sc)
     out["pM"] = gu.scale_invariante_martingale_regularization(mr, dtype(cases.LAM), sc)
-    if not heavy:
+    if shape != "cfg2":
         # quirk 1: a different (eps, L) request changes nothing
         out["loss_eps0p1_L5"] = gu.compute_sinkhorn_loss(real, fake, sc, 0.1, 5, hf, mr, hr, mf, video=True)
-        out["C_plain"] = gu.cost_xy(x, y, sc)
-        for eps, L in cases.EPS_L:
-            val, n = counted(tf, gu.compute_sinkhorn, x, y, hf, mr, sc, epsilon=dtype(eps), L=L)
-            key = "e%g_L%d" % (eps, L)
-            out["w_" + key] = val
-            out["nits_" + key] = n
-        val, n = counted(tf, gu.compute_sinkhorn, x, y, hf, mr, sc, hx=hr, My=mf, bi_causal=True)
-        out["w_bicausal"], out["nits_bicausal"] = val, n
-        out["C_bicausal"] = gu.bi_causal_modified_cost(x, y, hf, mr, hr, mf, sc)
-        val, n = counted(tf, gu.benchmark_sinkhorn, x, y, sc)
-        out["w_bench_default"], out["nits_bench_default"] = val, n
-        val, n = counted(tf, gu.benchmark_sinkhorn, x, y, sc, epsilon=dtype(0.8), L=50, Lmin=20)
-        out["w_bench_e0.8_L50_Lmin20"], out["nits_bench_e0.8_L50_Lmin20"] = val, n
-        out["N_m_real"] = gu.compute_N(mr)
+    out["C_plain"] = gu.cost_xy(x, y, sc)
+    for eps, L in cases.EPS_L:
+        val, n = counted(tf, gu.compute_sinkhorn, x, y, hf, mr, sc, epsilon=dtype(eps), L=L)
+        key = "e%g_L%d" % (eps, L)
+        out["w_" + key] = val
+        out["nits_" + key] = n
+    val, n = counted(tf, gu.compute_sinkhorn, x, y, hf, mr, sc, hx=hr, My=mf, bi_causal=True)
+    out["w_bicausal"], out["nits_bicausal"] = val, n
+    out["C_bicausal"] = gu.bi_causal_modified_cost(x, y, hf, mr, hr, mf, sc)
+    val, n = counted(tf, gu.benchmark_sinkhorn, x, y, sc)
+    out["w_bench_default"], out["nits_bench_default"] = val, n
+    val, n = counted(tf, gu.benchmark_sinkhorn, x, y, sc, epsilon=dtype(0.8), L=50, Lmin=20)
+    out["w_bench_e0.8_L50_Lmin20"], out["nits_bench_e0.8_L50_Lmin20"] = val, n
+    out["N_m_real"] = gu.compute_N(mr)
     res = {k + sfx: np.asarray(v) for k, v in out.items()}
     if dtype == np.float32:
         res["checksum"] = cases.checksum(inp)

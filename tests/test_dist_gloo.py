@@ -160,3 +160,12 @@ def test_sharded_hip_batch_128(protocol, tmp_path):
             g = g.cpu().double().numpy()
             np.testing.assert_allclose(out["d" + k].reshape(Bl, -1), g.reshape(B, -1)[r * Bl:(r + 1) * Bl], rtol=0,
                                        atol=2e-3 * np.abs(g).max(), err_msg=k)
+
+
+def test_data_parallel_trainer_draws_different_noise_per_rank(tmp_path):
+    """Default seed on both ranks: the constructor broadcasts rank 0's weights (identical replicas) and then
+    reseeds per rank, so the shards of the global batch are generated from DIFFERENT z (kernel_train.py:220,260
+    draws one z per sample of the batch)."""
+    res = launch(2, "small", 0, "near", "cpu", "noise", tmp_path)
+    assert np.array_equal(res[0]["p"], res[1]["p"])
+    assert res[0]["z"].shape == res[1]["z"].shape and not np.allclose(res[0]["z"], res[1]["z"])

@@ -117,3 +117,43 @@ def test_dataset_adapters_layouts():
     import pytest
     with pytest.raises(ValueError):
         ds.mmnist_videos(mm, 8)
+
+
+def test_shared_adam_counts_two_apply_gradients_per_step_like_keras():
+    """kernel_train.py:62-63,254-255,290-291: ONE Keras Adam per step kind, apply_gradients called once per
+    network -> `iterations` advances by 2 per training step, the schedule is read at the pre-increment count
+    (first update at lr(0) = 0), the bias correction uses t = iterations + 1.  The LR sequence is compared with the
+    reference's own WarmUp class (tests/golden/lr_schedule.npz, run 'short': lr 1e-3, warmup 6, decay 4 / 0.5)."""
+    import os
+    import numpy as np
+    import smooth_cases
+    from kccotgan_amd.kernel_train import KerasSharedAdam, warmup_exponential_decay
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lr_schedule.npz"))
+    lr, warmup, decay_steps, rate = smooth_cases.LR_RUNS["short"]
+    gold = dict(zip(g["steps"].tolist(), g["lr_short"].tolist()))
+    opt = KerasSharedAdam(lambda it: warmup_exponential_decay(it, lr, warmup, decay_steps, rate), beta_1=0.5, beta_2=0.9)
+    torch.manual_seed(0)
+    a, b = torch.randn(5, dtype=torch.float64), torch.randn(3, dtype=torch.float64)
+    a0, b0 = a.clone(), b.clone()
+    ma = va = np.zeros(5); mb = vb = np.zeros(3)
+    ra, rb = a0.numpy().copy(), b0.numpy().copy()
+    for step in range(4):                  # iterations 0..7 (all in the fixture; warm-up ends at 6)
+        ga, gb = torch.randn(5, dtype=torch.float64), torch.randn(3, dtype=torch.float64)
+        opt.apply_gradients([(ga, a)])
+        lr_a = opt.last_lr
+        opt.apply_gradients([(gb, b)])
+        lr_b = opt.last_lr
+        assert opt.iterations == 2 * (step + 1)
+        np.testing.assert_allclose([lr_a, lr_b], [gold[2 * step], gold[2 * step + 1]], rtol=2e-6)
+        # Keras Adam._resource_apply_dense, written out
+        for (gr, t, lr_t, which) in ((ga.numpy(), 2 * step + 1, lr_a, "a"), (gb.numpy(), 2 * step + 2, lr_b, "b")):
+            alpha = lr_t * np.sqrt(1 - 0.9 ** t) / (1 - 0.5 ** t)
+            if which == "a":
+                ma = 0.5 * ma + 0.5 * gr; va = 0.9 * va + 0.1 * gr * gr; ra = ra - alpha * ma / (np.sqrt(va) + 1e-7)
+            else:
+                mb = 0.5 * mb + 0.5 * gr; vb = 0.9 * vb + 0.1 * gr * gr; rb = rb - alpha * mb / (np.sqrt(vb) + 1e-7)
+        np.testing.assert_allclose(a.numpy(), ra, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(b.numpy(), rb, rtol=1e-12, atol=1e-15)
+        if step == 0:
+            assert torch.equal(a, a0)          # lr(0) = 0: the first network's first update is a no-op
+            assert not torch.equal(b, b0)

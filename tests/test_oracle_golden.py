@@ -89,6 +89,30 @@ def test_cfg2_cost_matrices_chunked():
     assert rel(w, g["w_xy"]) < 2e-5
 
 
+@pytest.mark.parametrize("seed,regime", [(0, "near"), (1, "far")])
+def test_cfg2_sinkhorn_variants_on_reference_cost_matrices(seed, regime):
+    """configs[1] full size: the (eps, L) / bi-causal / benchmark_sinkhorn variants, with the reference's own
+    cost matrices from the fixture as input (re-building them on the CPU takes 10 s each); cfg2_s1_far at
+    eps = 0.25 runs PAST Lmin (161 iterations in the reference's fp32, 168 in its fp64 run)."""
+    g, inp = load("cfg2", seed, regime)
+    for eps, L in cases.EPS_L:
+        key = "e%g_L%d" % (eps, L)
+        w, n = o.sinkhorn_from_cost(g["C_xy"], eps, L)[:2]
+        assert n == int(g["nits_" + key]) and rel(w, g["w_" + key]) < 2e-6, key
+        w64, n64 = o.sinkhorn_from_cost(g["C_xy_f64"], eps, L, dtype=np.float64)[:2]
+        assert n64 == int(g["nits_" + key + "_f64"]) and rel(w64, g["w_" + key + "_f64"]) < 1e-12, key
+    w, n = o.sinkhorn_from_cost(g["C_bicausal"])[:2]
+    assert n == int(g["nits_bicausal"]) and rel(w, g["w_bicausal"]) < 2e-6
+    w, n = o.sinkhorn_from_cost(g["C_plain"], 1.0, 10, 10, stop_on_index=True)[:2]
+    assert n == int(g["nits_bench_default"]) and rel(w, g["w_bench_default"]) < 2e-6
+    w, n = o.sinkhorn_from_cost(g["C_plain"], 0.8, 50, 20, stop_on_index=True)[:2]
+    assert n == int(g["nits_bench_e0.8_L50_Lmin20"]) and rel(w, g["w_bench_e0.8_L50_Lmin20"]) < 2e-6
+    # the causal terms on top of the plain matrix (gan_utils.py:34-38,60-68), from the oracle
+    caus = o.causal_term(inp["h_fake"], inp["m_real"], cases.SC)
+    np.testing.assert_allclose(g["C_plain"] + caus, g["C_xy"], rtol=2e-6)
+    np.testing.assert_allclose(g["C_xy"] + o.causal_term(inp["h_real"], inp["m_fake"], cases.SC), g["C_bicausal"], rtol=2e-6)
+
+
 def test_quirk2_lmin_and_late_stop():
     """gan_utils.py:149-160: exactly L iterations for L <= 100; for L > 100 the loop
     stops at the first iteration >= 100 whose sum|u - u_prev| < 1e-2."""
