@@ -2,8 +2,8 @@
 """Benchmark of the hot path: one step = one compute_sinkhorn_loss evaluation, forward + backward
 (gradients w.r.t. fake, h_fake, h_real, m_real, m_fake -- what the reference's generator step
 differentiates, kernel_train.py:287-289), on synthetic video already resident in HBM.  At N=1 the
-step is a hipGraph replay of the eight kernels (kccotgan_amd/graph.py; KCCOT_BENCH_EAGER=1 times
-eager launches instead, also reported as `eager_launches_ms_per_step`).
+step is a hipGraph replay of the kernels (kccotgan_amd/graph.py; KCCOT_BENCH_EAGER=1 times eager
+launches instead, also reported as `eager_launches_ms_per_step`).
 
 Workload = BASELINE.json configs[1]: Moving-MNIST shape [B=64, H=64, T=30, W=64, C=1], J=8,
 scaling_coef=1/15, epsilon=1, 100 Sinkhorn iterations (the as-called behaviour of the
@@ -12,16 +12,30 @@ reference: gan_utils.py:221-223).
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `value` = loss evaluations per second over the whole job;
-`ms_per_step` = the BASELINE "Sinkhorn-loss ms/iter".  `roofline` describes the dominant
-kernel of cost assembly (the K-split partial-Gram kernel), timed live with stream events, against
-its binding bound (SURVEY.md 8(d): the fp32 matrix peak at B = 64), with the HBM fraction beside it;
-`cpu_baseline` is the CPU oracle in the reference's own formulation timed on this box's host
-cores on a bounded sample (N=1, rank 0 only).
+Prints ONE JSON line (rank 0).
+  value / ms_per_step  loss evaluations per second / the BASELINE "Sinkhorn-loss ms/iter": EXACTLY K steps between
+                       two barriers, one wall-clock interval, max over ranks (the driver's contract).
+  event_timing         the same step replayed >= 100 more times with a HIP event between consecutive replays (on the
+                       stream the replays run on): median / p10 / p90 / min per step.
+  roofline             the dominant kernel of cost assembly (the K-split partial-Gram kernel) timed alone with stream
+                       events, against the BINDING bound of the pipe it executes on: the default kernel runs bf16
+                       MFMAs (exact 3-way split), whose ideal (6.0 us) is below the HBM ideal (7.9 us) -> bound "hbm",
+                       frac = algorithmic bytes / time / 8 TB/s.  The f32-MFMA-equivalent figure is a secondary key.
+                       `traffic` = PMC bytes per launch from the rocprofv3 pass named in `traffic_source`.
+  sinkhorn             the two latency-bound solver kernels timed alone: us per dependent half-step next to the
+                       exp-issue floor of one CU (4096 v_exp_f32 at 16 per cycle = 256 cycles).
+  train_steps_per_sec  the other half of BASELINE.json's metric: disc step + gen step (kernel_train.py:313-314) of the
+                       PyTorch-ROCm G/D around this loss at the configs[1] shape, a few iterations in a child
+                       process (bounded; MIOpen fast-find mode, stated in the block).
+  configs              fwd+bwd time of the other BASELINE configs: single-GPU equivalents at N=1; the sharded step
+                       at the N a config names when --gpus matches it.
+  cpu_baseline         the CPU oracle in the reference's own formulation on this box's host cores, bounded sample
+                       (N=1, rank 0 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,8 +48,17 @@ import torch         # noqa: E402
 
 SHAPE = dict(B=64, H=64, T=30, W=64, C=1, J=8)
 SC = 1.0 / 15.0
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+PEAK_CLOCK_GHZ = 2.4
+WRT = ("fake", "h_fake", "h_real", "m_real", "m_fake")
+# BASELINE.json configs[2..4]: name -> (B, H, T, W, C, L, GPUs named by the config)
+OTHER_CONFIGS = {
+    "configs[2]": (128, 64, 30, 64, 3, 100, 4),
+    "configs[3]": (256, 64, 30, 64, 3, 200, 8),
+    "configs[4]": (512, 128, 48, 128, 3, 300, 8),
+}
 
 
 def make_inputs(B, seed, device, regime="near"):
@@ -51,13 +74,42 @@ def make_inputs(B, seed, device, regime="near"):
 def loss_step(G, t):
     loss = G.compute_sinkhorn_loss(t["real"], t["fake"], SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"],
                                    t["m_fake"], video=True)
-    grads = torch.autograd.grad(loss, [t["fake"], t["h_fake"], t["h_real"], t["m_real"], t["m_fake"]])
+    grads = torch.autograd.grad(loss, [t[k] for k in WRT])
     return loss, grads
 
 
+def event_stats(step, reps):
+    """`reps` replays with an event recorded on the current stream between consecutive ones: per-step GPU durations
+    (the host queues ahead of the GPU, so consecutive events bracket exactly one step)."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for i in range(reps):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    d = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(reps)])
+    return {"reps": reps, "median_ms": float(np.median(d)), "p10_ms": float(np.percentile(d, 10)),
+            "p90_ms": float(np.percentile(d, 90)), "min_ms": float(d.min()), "mean_ms": float(d.mean()),
+            "clock": "HIP events on the replay stream"}
+
+
+def time_launches(launch, reps=200, warm=10):
+    for _ in range(warm):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3   # us
+
+
 def time_cost_kernel(t, reps=200):
-    """Average duration of the dominant cost kernel alone (KCCOT_COST_PARTIAL_ONLY), measured with
-    events on the stream the kernel is launched on (torch's current stream)."""
+    """Average duration of the dominant cost kernel alone (KCCOT_COST_PARTIAL_ONLY) and of the whole cost stage,
+    measured with events on the stream the kernels are launched on (torch's current stream)."""
     from kccotgan_amd import _lib
     from kccotgan_amd._lib import lib, ptr, stream_of, workspace, check
     B = t["real"].shape[0]
@@ -72,19 +124,39 @@ def time_cost_kernel(t, reps=200):
         check(lib.kccot_pairwise_cost3_f32(ptr(real), ptr(fake), B, K, SC, ptr(hf), ptr(hr), ptr(mr), ptr(mf),
                                            T, J, flags, ptr(C3), ws, wsb, stream_of(real)), "pairwise_cost3")
 
-    out = {}
-    for name, flags in (("partial", _lib.COST_PARTIAL_ONLY), ("stage", 0)):
-        for _ in range(10):
-            launch(flags)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            launch(flags)
-        e1.record()
-        torch.cuda.synchronize()
-        out[name] = e0.elapsed_time(e1) / reps * 1e3   # us
-    return out, K
+    out = {"partial": time_launches(lambda: launch(_lib.COST_PARTIAL_ONLY), reps),
+           "stage": time_launches(lambda: launch(0), reps)}
+    return out, K, C3
+
+
+def time_sinkhorn(C3, L=100, reps=50):
+    """The three-problem solve and its reverse sweep alone (every iteration executed: KCCOT_SK_NO_SHORTCUT=1 is set
+    by main): us per launch and per dependent half-step."""
+    from kccotgan_amd._lib import lib, ptr, stream_of, check
+    n = C3.shape[1]
+    dev = C3.device
+    uh, vh = torch.empty(3, L, n, device=dev), torch.empty(3, L, n, device=dev)
+    cost3, loss = torch.empty(3, device=dev), torch.empty(1, device=dev)
+    nits = torch.zeros(6, dtype=torch.int32, device=dev)
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+    g = torch.ones(1, device=dev)
+    dC3 = torch.empty_like(C3)
+    st = stream_of(C3)
+    fwd = lambda: check(lib.kccot_sinkhorn_divergence_fwd_f32(ptr(C3), n, 1.0, L, 100, 1e-2, ptr(uh), ptr(vh), ptr(cost3),
+                                                              ptr(nits), ptr(loss), ptr(ticket), None, 0, st), "sk_fwd")
+    bwd = lambda: check(lib.kccot_sinkhorn_divergence_bwd_f32(ptr(C3), ptr(uh), ptr(vh), ptr(nits), n, 1.0, L, ptr(g),
+                                                              ptr(dC3), None, 0, st), "sk_bwd")
+    f_us = time_launches(fwd, reps, 5)
+    b_us = time_launches(bwd, reps, 5)
+    its = int(nits[:3].max())
+    floor_us = 256.0 / (PEAK_CLOCK_GHZ * 1e3)
+    return {"n": n, "iterations": its, "fwd_us": f_us, "bwd_us": b_us,
+            "fwd_us_per_half_step": f_us / (2 * its), "bwd_us_per_half_step": b_us / (2 * its),
+            "fwd_cycles_per_half_step_at_2.4GHz": f_us / (2 * its) * PEAK_CLOCK_GHZ * 1e3,
+            "exp_issue_floor_cycles": 256, "exp_issue_floor_us_per_half_step": floor_us,
+            "fwd_over_floor": f_us / (2 * its) / floor_us,
+            "note": "one CU per problem: n*n v_exp_f32 per half-step at 16 lanes/cycle/CU (quarter rate) = 256 cycles; "
+                    "latency-bound chain, not a roofline fraction (SURVEY.md 8d)"}
 
 
 def cpu_baseline(inp, budget_s=25.0):
@@ -93,13 +165,13 @@ def cpu_baseline(inp, budget_s=25.0):
     threads torch uses.  Bounded: at least one evaluation, then as many as fit in the budget."""
     from oracle import gan_utils_torch as ot
     t = {k: torch.from_numpy(v) for k, v in inp.items()}
-    for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
+    for k in WRT:
         t[k].requires_grad_(True)
     n, t0 = 0, time.perf_counter()
     while True:
         loss = ot.compute_sinkhorn_loss(t["real"], t["fake"], SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"],
                                         t["m_fake"], video=True)
-        torch.autograd.grad(loss, [t["fake"], t["h_fake"], t["h_real"], t["m_real"], t["m_fake"]])
+        torch.autograd.grad(loss, [t[k] for k in WRT])
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or el + el / n > 1.6 * budget_s:
@@ -110,12 +182,109 @@ def cpu_baseline(inp, budget_s=25.0):
                 loss=float(loss))
 
 
+def train_steps_child(timeout_s=420):
+    """train-steps/sec in a CHILD process (a fault in stock MIOpen convolutions must not cost the headline line):
+    tools/bench_train.py at the configs[1] shape, MIOpen fast-find (first iteration ~10 s instead of ~290 s of
+    exhaustive solver search; steady state is slower than with the exhaustive search: DESIGN.md section 7)."""
+    env = dict(os.environ, MIOPEN_FIND_MODE="2", KCCOT_SK_NO_SHORTCUT="0")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_train.py"), "--json", "--iters", "3", "--kernel", "none"]
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            out, err = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            return {"value": None, "error": "child exceeded %d s" % timeout_s}
+        if p.returncode != 0:
+            return {"value": None, "error": "child exit code %d: %s" % (p.returncode, err.strip()[-300:])}
+        r = json.loads(out.strip().splitlines()[-1])
+    except Exception as e:
+        return {"value": None, "error": repr(e)}
+    return {"value": r["train_steps_per_sec"], "unit": "train-steps/s (disc step + gen step)",
+            "ms_per_train_step": r["ms_per_train_step"], "iterations_timed": r["iterations"],
+            "first_iteration_s": r["first_iteration_s"],
+            "config": "B=64, T=30 (5 context + 25 predicted), 64x64x1, filter sizes 8, z 128, kernel=none, "
+                      "PyTorch-ROCm G/D (MIOpen, MIOPEN_FIND_MODE=2 fast find, faulting NHWC bwd solver off) + HIP loss path",
+            "pM": r["pm"], "loss": r["loss"], "child_wall_s": time.perf_counter() - t0}
+
+
+def config_inputs(B, H, T, W, C, dev, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    real = torch.rand((B, H, T, W, C), device=dev, generator=g)
+    fake = (real + 0.05 * torch.randn(real.shape, device=dev, generator=g)).clamp_(0, 1)
+    t = {"real": real, "fake": fake}
+    for k in ("h_fake", "m_real", "h_real", "m_fake"):
+        t[k] = torch.rand((B, T, SHAPE["J"]), device=dev, generator=g)
+    return t
+
+
+def single_gpu_configs(G, dev):
+    """One-GPU fwd+bwd time of BASELINE configs[2..4] at full size (what every rank of the sharded path would do
+    without the all-gather, plus all row blocks instead of B/G of them).  L > 100 through honor_eps_l (the
+    keyword route of the reference, gan_utils.py:124); the executed iteration counts are reported."""
+    out = {}
+    for name, (B, H, T, W, C, L, ngpu) in OTHER_CONFIGS.items():
+        t = config_inputs(B, H, T, W, C, dev)
+        for k in WRT:
+            t[k].requires_grad_(True)
+
+        def step():
+            loss = G.compute_sinkhorn_loss(t["real"], t["fake"], SC, 1.0, L, t["h_fake"], t["m_real"], t["h_real"],
+                                           t["m_fake"], honor_eps_l=True)
+            return loss, torch.autograd.grad(loss, [t[k] for k in WRT])
+
+        loss, grads = step()
+        torch.cuda.synchronize()
+        reps = 5 if B <= 256 else 2
+        st = event_stats(step, reps)
+        K = H * T * W * C
+        alg_bytes = 2 * B * K * 4 + 16 * B * T * SHAPE["J"] + 12 * B * B
+        out[name] = {"B": B, "K": K, "L": L, "gpus_named_by_config": ngpu, "n_gpus_here": 1,
+                     "ms_fwd_bwd_median": st["median_ms"], "ms_fwd_bwd_min": st["min_ms"], "reps": reps,
+                     "sinkhorn_iters": G.last_info["compute_sinkhorn_loss"].tolist(),
+                     "loss": float(loss), "finite": bool(torch.isfinite(grads[0]).all()),
+                     "algorithmic_MB_fwd": alg_bytes / 1e6, "algorithmic_GFLOP_fwd": 4 * B * B * K / 1e9,
+                     "ideal_ms_fwd_hbm": alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                     "ideal_ms_fwd_f32_mfma": 4 * B * B * K / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3}
+        del t, grads, loss
+        torch.cuda.empty_cache()
+    return out
+
+
+def sharded_config(name, rank, world, dev, dist, barrier, steps=5):
+    """The batch-sharded step (kccotgan_amd.dist, gather protocol unless KCCOT_DIST_PROTOCOL says otherwise) of the
+    BASELINE config that names this GPU count, global batch fixed (strong scaling of that config)."""
+    from kccotgan_amd import dist as kd
+    B, H, T, W, C, L, ngpu = OTHER_CONFIGS[name]
+    Bl = B // world
+    t = config_inputs(Bl, H, T, W, C, dev, seed=100 + rank)       # this rank's shard only
+    shard = {k: v.requires_grad_(k != "real") for k, v in t.items()}
+    step = lambda: kd.sharded_loss_step(shard, SC, epsilon=1.0, L=L)
+    loss, _ = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _g = step()
+    barrier()
+    el = time.perf_counter() - t0
+    tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    K = H * T * W * C
+    return {"B": B, "K": K, "L": L, "n_gpus_here": world, "ms_fwd_bwd": float(tt) / steps * 1e3, "steps": steps,
+            "protocol": os.environ.get("KCCOT_DIST_PROTOCOL", "gather"), "loss": float(loss),
+            "sinkhorn_iters": kd.last_info["nits"].tolist() if "nits" in kd.last_info else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the train-steps/sec child process")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs[2..4] block")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +317,7 @@ def main():
     # shipped default (shortcut on, bit-identical results) is timed separately below.
     os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
     inp, t = make_inputs(SHAPE["B"], 0, dev)
-    for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
+    for k in WRT:
         t[k].requires_grad_(True)
 
     mode = "eager launches"
@@ -183,8 +352,8 @@ def main():
         step = lambda: loss_step(G, t)
     else:
         # the step as a training loop would run it: forward + backward captured once into a hipGraph
-        # (kccotgan_amd/graph.py) and replayed -- the same eight kernels with the same arguments, one
-        # hipGraphLaunch instead of eight launches issued from Python
+        # (kccotgan_amd/graph.py) and replayed -- the same kernels with the same arguments, one
+        # hipGraphLaunch instead of several launches issued from Python
         try:
             from kccotgan_amd.graph import GraphedLossStep
             graphed = GraphedLossStep(t, SC)
@@ -238,6 +407,16 @@ def main():
                    "sinkhorn_iters": nits, "sinkhorn_iters_executed": nexec, "sinkhorn_exact_shortcut": "off",
                    "launch": mode, "loss": float(loss)},
     }
+    # ---- per-step distribution with HIP events (all ranks replay -- the sharded step has collectives; rank 0 reports)
+    try:
+        reps = max(100, args.steps)
+        st = event_stats(step, reps)
+        if rank == 0:
+            out["event_timing"] = st
+    except Exception as e:
+        sys.stderr.write("bench: event timing failed: %r\n" % (e,))
+    barrier()
+
     if rank == 0 and world == 1:
       try:
         # the shipped default: exact shortcut on.  Same outputs bit for bit (tests/test_gpu_parity.py::
@@ -260,7 +439,7 @@ def main():
             _, tr = make_inputs(SHAPE["B"], seed, dev, regime)
             gs = GraphedLossStep(tr, SC)
             ms_g, (l2, _g) = timed(lambda: gs())
-            for k in ("fake", "h_fake", "h_real", "m_real", "m_fake"):
+            for k in WRT:
                 tr[k].requires_grad_(True)
             ms_e, _r = timed(lambda: loss_step(G, tr))
             extra[regime] = {"ms_per_step": ms_g, "ms_per_step_eager_launches": ms_e, "loss": float(l2),
@@ -273,43 +452,77 @@ def main():
         os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
     if rank == 0:       # the dominant kernel is the same on every rank at any N (replicated cost assembly at B <= 64)
       try:
-        kt, K = time_cost_kernel(t)
+        kt, K, C3 = time_cost_kernel(t)
         B, T, J = SHAPE["B"], SHAPE["T"], SHAPE["J"]
         alg_bytes = 2 * B * K * 4 + 16 * B * T * J + 12 * B * B            # read real+fake once
         alg_flops = 4 * B * B * K                                          # xy full + xx, yy triangles (8(d))
         f32_path = os.environ.get("KCCOT_GRAM_F32") == "1"
         t_s = kt["partial"] * 1e-6
-        traffic = None
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
-            traffic = json.load(open(tf)).get("gram128_partial_bytes_per_launch")
+            rec = json.load(open(tf))
+            traffic = rec.get("gram128_partial_bytes_per_launch")
+            traffic_source = rec.get("source", "profiles/hbm_traffic.json (committed rocprofv3 --pmc pass, not measured in this run)")
         hbm = alg_bytes / t_s / 1e9
+        tfl = alg_flops / t_s / 1e12
+        ideal_hbm_us = alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e6
         if f32_path:
-            # f32-input MFMA kernel: ideal 12.8 us on the MFMA pipe vs 7.9 us of HBM -> MFMA-bound
+            # f32-input MFMA kernel: ideal 12.8 us on the f32 MFMA pipe vs 7.9 us of HBM -> MFMA-bound
             exec_flops = 10 * 2 * 32 * 32 * K
-            roof = {"kernel": "gram128_partial<f32 MFMA>", "bound": "mfma", "achieved": alg_flops / t_s / 1e12,
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flops / t_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                    "executed_mfma_tflops": exec_flops / t_s / 1e12}
+            roof = {"kernel": "gram128_partial<f32 MFMA>", "bound": "mfma", "achieved": tfl,
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F32_PEAK_TFLOPS,
+                    "executed_mfma_tflops": exec_flops / t_s / 1e12,
+                    "ideal_us": {"hbm": ideal_hbm_us, "f32_mfma": alg_flops / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e6},
+                    "hbm_achieved_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS}
         else:
-            # Binding bound per SURVEY.md 8(d): the larger ideal time.  fp32 arithmetic at B = 64 is MFMA-bound
-            # (4*B^2*K = 2.01 GFLOP at the 157.3 TFLOP/s f32 matrix peak = 12.8 us) rather than HBM-bound (62.9 MB at
-            # 8 TB/s = 7.9 us), and the kernel is measured matrix-pipe bound.  `achieved` is
-            # ALGORITHMIC fp32 flops / time.  The kernel executes them as six exact bf16 products per entry
-            # (15.1 GFLOP on the bf16 pipe): that rate and the HBM fraction are reported beside it.
+            # The kernel issues v_mfma_f32_32x32x16_bf16 (exact three-way split, six products): on the pipe it
+            # executes on the ideals are 15.1 GFLOP / 2.5 PFLOP/s = 6.0 us (bf16 MFMA) against 62.9 MB / 8 TB/s
+            # = 7.9 us (HBM) -> the BINDING bound is HBM, and `frac` is the HBM fraction the north star asks for.
             exec_flops = 6 * 10 * 2 * 32 * 32 * K
-            tfl = alg_flops / t_s / 1e12
-            roof = {"kernel": "gram128_partial_x3ws", "bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": tfl / MFMA_F32_PEAK_TFLOPS,
+            roof = {"kernel": "gram128_partial_x3ws", "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                    "ideal_us": {"hbm": ideal_hbm_us, "bf16_mfma_executed": exec_flops / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e6,
+                                 "f32_mfma_equivalent": alg_flops / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e6},
                     "executed_bf16_mfma_tflops": exec_flops / t_s / 1e12,
-                    "bf16_mfma_frac": exec_flops / t_s / 1e12 / 2500.0}
-        roof.update({"traffic": traffic, "kernel_us": kt["partial"], "cost_stage_us": kt["stage"],
-                     "hbm_achieved_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
-                     "algorithmic_flops": alg_flops})
+                    "bf16_mfma_frac": exec_flops / t_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "f32_mfma_equivalent": {"achieved_tflops": tfl, "peak": MFMA_F32_PEAK_TFLOPS,
+                                            "frac": tfl / MFMA_F32_PEAK_TFLOPS,
+                                            "note": "algorithmic fp32 flops / time against the f32-input MFMA peak; "
+                                                    "applies to KCCOT_GRAM_F32=1, secondary here"}}
+        roof.update({"traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                     "kernel_us": kt["partial"], "cost_stage_us": kt["stage"],
+                     "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
+                     "timing": "200 launches between two events on the launch stream"})
         out["roofline"] = roof
+        out["sinkhorn"] = time_sinkhorn(C3)
       except Exception as e:
         sys.stderr.write("bench: roofline block failed: %r\n" % (e,))
+    # ---- the other BASELINE configs
+    if not args.no_configs:
+        cfgs = None
+        try:
+            if world == 1:
+                cfgs = single_gpu_configs(G, dev)
+            else:
+                cfgs = {}
+                for name, c in OTHER_CONFIGS.items():
+                    if c[6] == world and c[0] % world == 0:      # every rank takes the same branch: world is global
+                        cfgs[name] = sharded_config(name, rank, world, dev, dist, barrier)
+        except Exception as e:
+            sys.stderr.write("bench: configs block failed on rank %d: %r\n" % (rank, e))
+        if rank == 0 and cfgs:
+            out["configs"] = cfgs
+    if rank == 0 and world == 1:
       try:
-        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
+        if not args.no_train:
+            torch.cuda.empty_cache()
+            out["train_steps_per_sec"] = train_steps_child()
+      except Exception as e:
+        sys.stderr.write("bench: train_steps_per_sec failed: %r\n" % (e,))
+      try:
+        if not args.no_cpu_baseline:      # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(inp)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
       except Exception as e:

@@ -371,12 +371,12 @@ def sharded_sinkhorn_loss(f_real_l, f_fake_l, scaling_coef, h_fake_l, m_real_l, 
     cast = (lambda v: v.float()) if ops is HipOps else (lambda v: v)   # the HIP kernels are fp32
     flat = lambda v: cast(v.reshape(Bl, -1)).contiguous()
     feat = lambda v: cast(v).contiguous()
-    # protocol: "gather" (all-gather the batch; replicated assembly at B <= 64, row blocks above), "ksplit" (shard the
-    # contraction), or "auto" (default): ksplit for batches above 64 when the shape allows it -- there the gather
-    # protocol moves G shards to every rank and builds its row blocks on the VALU kernel, while the sliced Gram and
-    # video-gradient kernels scale 7.6-9.9x on 8 ranks -- and gather for B <= 64, where the
-    # replicated Sinkhorn dominates either way and the all-gather protocol is the one the north star prescribes
-    protocol = protocol or os.environ.get("KCCOT_DIST_PROTOCOL", "auto")
+    # protocol: "gather" (the default, and what BASELINE.json's north star prescribes: all-gather the batch; replicated
+    # assembly at B <= 64, row blocks above), "ksplit" (opt-in: shard the contraction -- all-to-all into K-slices,
+    # all-reduced fp64 Gram sums; by byte counts and per-rank kernel times it should win above B = 64, DESIGN.md
+    # section 6, but it has never been timed on more than one GPU, so it stays opt-in until a SCALE record exists),
+    # or "auto" (ksplit above B = 64 when the shape allows it, gather otherwise).
+    protocol = protocol or os.environ.get("KCCOT_DIST_PROTOCOL", "gather")
     if protocol not in ("auto", "gather", "ksplit"):
         raise ValueError("unknown protocol %r" % (protocol,))
     if protocol == "auto":
@@ -409,8 +409,8 @@ def shard_batch(t, rank, world):
     return out
 
 
-def sharded_loss_step(shard, sc, group=None):
+def sharded_loss_step(shard, sc, group=None, epsilon=1.0, L=100, protocol=None):
     loss = sharded_sinkhorn_loss(shard["real"], shard["fake"], sc, shard["h_fake"], shard["m_real"], shard["h_real"],
-                                 shard["m_fake"], group)
+                                 shard["m_fake"], group, epsilon=epsilon, L=L, protocol=protocol)
     grads = torch.autograd.grad(loss, [shard[k] for k in ("fake", "h_fake", "h_real", "m_real", "m_fake")])
     return loss, grads

@@ -69,7 +69,7 @@ def run(rank, world, port, shape, seed, regime, device, use_hip, out_path):
         from kccotgan_amd.graph import GraphedShardedStep, GraphedKSplitStep
         from kccotgan_amd import dist as _kd
         B_, K_ = inp["real"].shape[0], int(np.prod(inp["real"].shape[1:]))
-        proto = os.environ.get("KCCOT_DIST_PROTOCOL", "auto")
+        proto = os.environ.get("KCCOT_DIST_PROTOCOL", "gather")
         if proto == "auto":
             proto = "ksplit" if (B_ > 64 and _kd.ksplit_supported(B_, K_, world)) else "gather"
         cls = GraphedKSplitStep if proto == "ksplit" else GraphedShardedStep

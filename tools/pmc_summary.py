@@ -32,5 +32,7 @@ json.dump(summary, open(os.path.join(out, "hbm_traffic_all.json"), "w"), indent=
 g = [v for k, v in summary.items() if k.startswith("gram128_partial")]
 if g:
     json.dump({"gram128_partial_bytes_per_launch": g[0]["hbm_bytes_per_launch"], "detail": g[0],
+               "source": "rocprofv3 --pmc pass '%s' (tools/pmc.sh; copy of its summary under profiles/); read from this "
+                         "file by bench.py, not re-measured in the bench run" % os.path.basename(os.path.normpath(out)),
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB units, FETCH_SIZE x2 (gfx950 wide-read correction)"},
               open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
