@@ -30,10 +30,11 @@
 extern "C" {
 #endif
 
-#define KCCOT_VERSION 100          /* 0.1.0 */
+#define KCCOT_VERSION 200          /* 0.2.0 */
 #define KCCOT_EINVAL (-1)          /* bad shape / null pointer / inconsistent arguments      */
 #define KCCOT_EUNSUPPORTED (-2)    /* valid request outside what this build implements       */
 #define KCCOT_EWORKSPACE (-3)      /* workspace too small                                    */
+#define KCCOT_EABORTED (-4)        /* a multi-CU Sinkhorn solve gave up (kccot_sinkhorn_status) */
 
 /* cost flags */
 #define KCCOT_COST_SAME 1u         /* x and y are the same tensor: upper triangle computed,   */
@@ -149,6 +150,17 @@ int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float eps, int L, i
                            float thresh, int stop_mode, float* u_hist, float* v_hist,
                            float* cost_out, int32_t* nits_out, float* pi_out,
                            void* ws, size_t ws_bytes, kccot_stream_t stream);
+
+/* Status of finished solves.  The multi-CU solver (128 < n <= 1024) spreads a problem over several workgroups
+ * that exchange duals by polling; it is only launched when the device can hold all of them at once (CU count x
+ * occupancy, queried at run time; otherwise the one-workgroup streaming solver runs), and its polling is bounded:
+ * should a workgroup never show up, the solve drains within about a second, writes NaN to cost_out[p] and a
+ * NEGATIVE count to nits_out[p], and the reverse sweep of that problem writes NaN gradients -- never a plausible
+ * number.  This call makes that visible to a host that does not want to look for NaN: it WAITS for `stream`,
+ * copies nits[0..nprob) to the host and returns 0 or KCCOT_EABORTED.  (The reference has no counterpart: its loop
+ * is a host loop, gan_utils.py:151-160.)  Synchronising by design -- call it where a NaN guard would sit
+ * (kernel_train.py:323), not per step. */
+int kccot_sinkhorn_status(const int32_t* nits, int nprob, kccot_stream_t stream);
 
 /* Reverse sweep through the executed iterations (what tf.GradientTape does through the unrolled
  * loop, kernel_train.py:221,252,262,289): dC_out[p] = gcost[p] * dcost[p]/dC[p].  gcost is a

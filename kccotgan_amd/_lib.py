@@ -12,7 +12,7 @@ import torch  # must be imported first: the library then binds to the HIP runtim
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkccot.so")
 
-EINVAL, EUNSUPPORTED, EWORKSPACE = -1, -2, -3
+EINVAL, EUNSUPPORTED, EWORKSPACE, EABORTED = -1, -2, -3, -4
 
 COST_SAME, COST_FORCE_DIRECT, COST_FORCE_MFMA, COST_PARTIAL_ONLY = 1, 2, 4, 8
 COST_GRAM_SUMS_ONLY, COST_FROM_GRAM_SUMS = 16, 32
@@ -45,6 +45,7 @@ SIGNATURES = {
                                          _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "kccot_sinkhorn_workspace_bytes": (_sz, [_i, _i]),
     "kccot_sinkhorn_fwd_f32": (_i, [_fp, _i, _i, _f, _i, _i, _f, _i, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_sinkhorn_status": (_i, [_fp, _i, _fp]),
     "kccot_sinkhorn_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _i, _fp, _fp, _fp, _sz, _fp]),
     "kccot_sinkhorn_divergence_fwd_f32": (_i, [_fp, _i, _f, _i, _i, _f, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "kccot_sinkhorn_divergence_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _f, _i, _fp, _fp, _fp, _sz, _fp]),

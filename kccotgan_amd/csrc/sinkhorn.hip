@@ -620,6 +620,20 @@ extern "C" int kccot_sinkhorn_fwd_f32(const float* C, int nprob, int n, float ep
     return launch_status("sinkhorn_fwd_reg");
 }
 
+extern "C" int kccot_sinkhorn_status(const int32_t* nits, int nprob, kccot_stream_t stream) {
+    if (!nits || nprob <= 0 || nprob > 4096) return fail(KCCOT_EINVAL, "sinkhorn_status: bad arguments");
+    int32_t host[4096];
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(host, nits, sizeof(int32_t) * nprob, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(KCCOT_EINVAL, "sinkhorn_status: could not read the iteration counts");
+    for (int p = 0; p < nprob; ++p)
+        if (host[p] < 0)
+            return fail(KCCOT_EABORTED, "sinkhorn: problem %d of %d was aborted -- a workgroup of the multi-CU solver never "
+                        "arrived (device shared or partitioned?); set KCCOT_SK_NO_COOP=1 to use the one-workgroup solver", p, nprob);
+    return 0;
+}
+
 extern "C" int kccot_sinkhorn_bwd_f32(const float* C, const float* u_hist, const float* v_hist,
                                       const int32_t* nits, int nprob, int n, float eps, int L,
                                       const float* gcost, float* dC_out, void* ws, size_t ws_bytes,

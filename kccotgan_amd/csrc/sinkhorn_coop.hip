@@ -197,7 +197,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_coop(SinkCoopArgs a) 
         float s = 0.f;
         for (unsigned k = 0; k < nwg; ++k) s += ld_agent(a.costp + p * SC_MAXWG + k);
         a.cost_out[p] = ok ? s : NAN;      // an aborted solve (see grid_barrier) must not look like a result
-        a.nits_out[p] = nits;
+        a.nits_out[p] = ok ? nits : -1;    // negative count = aborted (kccot_sinkhorn_status)
         a.nits_out[gridDim.y + p] = nits;
     }
 }
@@ -233,6 +233,13 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_coop(SinkCoopBwdArgs 
     float* xgv = a.xgv + (int64_t)p * n;
     const float eps = a.eps, inv_eps = a.inv_eps, g = a.gcost[p];
     const int nits = a.nits[p];
+    if (nits < 0) {          // aborted forward solve: NaN gradient, every workgroup of the problem leaves before any barrier
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = lane + 64 * e;
+            if (live && idx < n) { a.dC[((int64_t)p * n + line) * n + idx] = NAN; a.dCT[((int64_t)p * n + line) * n + idx] = NAN; }
+        }
+        return;
+    }
     const float* uh = a.u_hist + (int64_t)p * a.L * n;     // history index k holds (u_{k+1}, v_{k+1}); u_0 = v_0 = 0
     const float* vh = a.v_hist + (int64_t)p * a.L * n;
     const float aconst = eps * logf(1.0f / (float)n);
@@ -389,6 +396,7 @@ struct SinkLLArgs {
     ll_word* xv;      // [nprob][n]
     ll_word* xcost;   // [nprob][SC_MAXWG]
     int nwg, nprob, xcd_map;
+    int fault;        // fault injection (KCCOT_SK_FAULT_INJECT=1, tests only): the last workgroup of problem 0 never takes part
 };
 
 // blockIdx -> (problem, workgroup of the problem).  xcd_map: workgroups are dealt round-robin to the 8 XCDs, so
@@ -407,6 +415,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
     __shared__ int bflag;
     int p, wg;
     if (!ll_role(a.xcd_map, a.nwg, a.nprob, p, wg)) return;
+    if (a.fault && p == 0 && wg == a.nwg - 1) return;      // stands in for a workgroup that is not resident
     const int n = a.n, nwg = a.nwg;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int line = wg * SC_LINES + w;
@@ -513,8 +522,8 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
         float s = 0.f;
         for (int q = 0; q < nwg; ++q) s += __shfl(val, q, 64);
         if (lane == 0) {
-            a.cost_out[p] = dead ? NAN : s;      // an aborted solve must not look like a result
-            a.nits_out[p] = nits;
+            a.cost_out[p] = dead ? NAN : s;      // an aborted solve must not look like a result ...
+            a.nits_out[p] = dead ? -1 : nits;    // ... and says so: a negative count is the status the host reads (kccot_sinkhorn_status)
             a.nits_out[a.nprob + p] = nits;
         }
     }
@@ -553,6 +562,13 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
     ll_word* xgv = a.xgv + (int64_t)p * n;
     const float eps = a.eps, inv_eps = a.inv_eps, g = a.gcost[p];
     const int nits = a.nits[p];
+    if (nits < 0) {          // the forward solve of this problem was aborted: every workgroup of it writes NaN and leaves
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = lane + 64 * e;
+            if (live && idx < n) { a.dC[((int64_t)p * n + line) * n + idx] = NAN; a.dCT[((int64_t)p * n + line) * n + idx] = NAN; }
+        }
+        return;
+    }
     const float* uh = a.u_hist + (int64_t)p * a.L * n;     // history index k holds (u_{k+1}, v_{k+1}); u_0 = v_0 = 0
     const float* vh = a.v_hist + (int64_t)p * a.L * n;
     const float aconst = eps * logf(1.0f / (float)n);
@@ -657,9 +673,44 @@ static bool coop_enabled() {
     return !(e && atoi(e) == 1);
 }
 
+// How many 1024-thread workgroups of the cooperative kernels the current device can hold AT ONCE: the spin-wait
+// exchanges are only safe when every workgroup of a launch is resident (a workgroup that has not started cannot
+// publish what its siblings poll for).  multiProcessorCount x the occupancy of the fattest instantiation (EPT = 16,
+// reverse sweep), queried once per device; three quarters of it are offered, so that a co-running kernel (an RCCL
+// collective of the data-parallel trainer, another stream) does not turn a legal launch into a bounded-poll abort.
+// A partitioned / CU-masked / smaller device simply reports fewer CUs and larger batches take the streaming solver.
+// KCCOT_SK_COOP_MAX_WG=<n> overrides the result (tests: force the fallback by capacity).
+static int coop_capacity() {
+    static int cached[64];
+    static bool have[64];
+    if (const char* e = getenv("KCCOT_SK_COOP_MAX_WG")) return atoi(e);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!have[dev]) {
+        int cus = 0, per_cu = 0, m = 1 << 30;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+#define KCCOT_OCC(K)                                                                                              \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K, SC_THREADS, 0) != hipSuccess) per_cu = 0;        \
+        m = per_cu < m ? per_cu : m;
+        KCCOT_OCC(sinkhorn_fwd_ll<4>) KCCOT_OCC(sinkhorn_fwd_ll<8>) KCCOT_OCC(sinkhorn_fwd_ll<16>)
+        KCCOT_OCC(sinkhorn_bwd_ll<4>) KCCOT_OCC(sinkhorn_bwd_ll<8>) KCCOT_OCC(sinkhorn_bwd_ll<16>)
+        KCCOT_OCC(sinkhorn_fwd_coop<4>) KCCOT_OCC(sinkhorn_fwd_coop<8>) KCCOT_OCC(sinkhorn_fwd_coop<16>)
+        KCCOT_OCC(sinkhorn_bwd_coop<4>) KCCOT_OCC(sinkhorn_bwd_coop<8>) KCCOT_OCC(sinkhorn_bwd_coop<16>)
+#undef KCCOT_OCC
+        cached[dev] = (int)((long long)cus * m * 3 / 4);
+        have[dev] = true;
+    }
+    return cached[dev];
+}
+
 bool sinkhorn_coop_eligible(int nprob, int n) {
     const int nwg = (n + SC_LINES - 1) / SC_LINES;
-    return coop_enabled() && n > 128 && n <= 1024 && nprob <= 32 && nwg * nprob <= 192;   // all workgroups resident
+    return coop_enabled() && n > 128 && n <= 1024 && nprob <= 32 && nwg * nprob <= coop_capacity();   // all workgroups resident
+}
+
+static int fault_injected() {
+    const char* e = getenv("KCCOT_SK_FAULT_INJECT");   // tests only: one workgroup of problem 0 stays away (abort path)
+    return (e && atoi(e) == 1) ? 1 : 0;
 }
 
 struct CoopCarve { CoopCtrl* ctrl; float* x0; float* x1; float* e0; float* e1; float* second; };
@@ -710,7 +761,7 @@ int launch_sinkhorn_fwd_coop(const float* C, int nprob, int n, float eps, int L,
         const int nwg = (n + SC_LINES - 1) / SC_LINES;
         const int xm = ll_xcd_map(nprob, nwg) ? 1 : 0;
         SinkLLArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
-                     lv.ctrl, lv.x0, lv.x1, lv.xc, nwg, nprob, xm};
+                     lv.ctrl, lv.x0, lv.x1, lv.xc, nwg, nprob, xm, fault_injected()};
         const dim3 grid = xm ? dim3(8 * nwg) : dim3(nwg, nprob);
         const int ept = (n + 63) / 64;
 #define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_fwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)

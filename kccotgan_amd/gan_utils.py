@@ -15,7 +15,7 @@ from ._lib import lib, check, ptr, stream_of, workspace
 
 __all__ = ["cost_xy", "modified_cost", "bi_causal_modified_cost", "benchmark_sinkhorn",
            "compute_sinkhorn", "compute_N", "scale_invariante_martingale_regularization",
-           "compute_sinkhorn_loss", "last_info"]
+           "compute_sinkhorn_loss", "last_info", "raise_if_solver_aborted"]
 
 # executed Sinkhorn iteration counts (device int32 tensors, no host sync) of the latest calls;
 # the reference keeps them in a local (gan_utils.py:148,158) although its docstring promises them
@@ -418,3 +418,19 @@ def compute_sinkhorn_loss(f_real, f_fake, scaling_coef, sinkhorn_eps, sinkhorn_l
     # one library call each way; equivalent to _Cost3 (C3 = [xy, xx, yy]) followed by _SinkhornDivergence
     return _SinkhornLoss.apply(real, fake, _feat(h_fake), _feat(h_real), _feat(m_real), _feat(m_fake),
                                float(scaling_coef), eps, L, _LMIN, "compute_sinkhorn_loss")
+
+
+def raise_if_solver_aborted():
+    """Synchronising status check of the most recent solves (``kccot_sinkhorn_status``): raises ``KccotError`` if a
+    multi-CU Sinkhorn solve gave up (negative iteration count; its cost and gradients are NaN).  The training loop
+    calls it where the reference has its non-finite-loss guard (kernel_train.py:323), so that an aborted solve is
+    reported as what it is and not as an exploded loss."""
+    for tag in ("compute_sinkhorn_loss", "compute_sinkhorn", "benchmark_sinkhorn"):
+        nits = last_info.get(tag)
+        if nits is None or not torch.is_tensor(nits) or not nits.is_cuda:
+            continue
+        nits = nits.contiguous()
+        rc = lib.kccot_sinkhorn_status(ptr(nits), int(nits.numel()), stream_of(nits))
+        if rc == _lib.EABORTED:
+            raise _lib.KccotError("%s: %s" % (tag, lib.kccot_last_error().decode("utf-8", "replace")))
+        check(rc, "sinkhorn_status")

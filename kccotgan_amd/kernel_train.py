@@ -256,6 +256,7 @@ class KCCOTTrainer:
                 log("pM", pm, it_counts)
                 log("Sinkhorn Loss", loss, it_counts)
             if not math.isfinite(loss):                                          # :323
+                gan_utils.raise_if_solver_aborted()        # an aborted multi-CU solve is an error, not an exploded loss
                 exploded = True
                 break
             if test_x is not None and (it_counts % save_freq == 0 or it_counts == 1) and log is not None:   # :331

@@ -63,5 +63,25 @@ for _ in range(100):
     ks()
 torch.cuda.synchronize()
 print("graphed ksplit step (world 1, nccl calls in place): %.1f us/step" % ((time.perf_counter() - t0) / 100 * 1e6))
+# raw collectives the contraction-sharded protocol uses, on device tensors
+a2a_in = torch.arange(8, dtype=torch.float32, device=dev)
+a2a_out = torch.empty_like(a2a_in)
+dist.all_to_all_single(a2a_out, a2a_in)
+s64 = torch.tensor([1.25, 2.5], dtype=torch.float64, device=dev)
+dist.all_reduce(s64, op=dist.ReduceOp.SUM)
+torch.cuda.synchronize()
+assert torch.equal(a2a_out, a2a_in) and s64.tolist() == [1.25, 2.5]
+# sharded kernel smoothing: all_reduce(MAX) of the maxima, all_reduce(SUM) of the adjoint's two sums (RCCL, fp32)
+from kccotgan_amd.data_utils import KernelSmoothing
+v = torch.rand(2, 16, 12, 16, 1, device=dev)
+outs = {}
+for sharded in (False, True):
+    xv = v.clone().requires_grad_(True)
+    o3 = KernelSmoothing(6, 6, sharded=sharded).gaussian_convolution3D(xv, 2.0)
+    o3.backward(torch.ones_like(o3) * 0.5 + v)
+    outs[sharded] = (o3.detach(), xv.grad)
+torch.cuda.synchronize()
+assert torch.equal(outs[True][0], outs[False][0])
+assert float((outs[True][1] - outs[False][1]).abs().max()) <= 2e-6 * float(outs[False][1].abs().max())
 print("nccl selftest ok: backend=%s loss=%.6f" % (dist.get_backend(), float(loss)))
 dist.destroy_process_group()
