@@ -188,9 +188,18 @@ __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
     const int bbase = same ? 0 : TP;                          // a diagonal pair reads the B fragments from the A rows
     const int boff0 = (bbase + 64 * wc) * TPITCH + lo, boff1 = boff0 + 32 * TPITCH;
 
-    tf32x16 acc00, acc01, acc10, acc11;
+    // Two-level fp32 accumulation.  One K-chunk is up to ~37 000 columns at configs[4] (B = 512: 64 chunks of
+    // K = 2 359 296), i.e. ~14 000 MFMA accumulations into ONE fp32 register -- measured at full size against the fp64
+    // oracle: the all-positive sums G_ee[j,j] (the near-regime diagonal of C_xy) came out 2.3e-5 low.  The MFMA
+    // accumulators therefore only run over TFLUSH stages (96 accumulations) and are then folded into a second set of
+    // fp32 sums (144 additions per chunk at that size): 64 v_add per 384 MFMAs, and the chunk sums stay fp64.
+    constexpr int TFLUSH = 8;
+    tf32x16 acc00, acc01, acc10, acc11, sum00, sum01, sum10, sum11;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+        acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f;
+        sum00[r] = 0.f; sum01[r] = 0.f; sum10[r] = 0.f; sum11[r] = 0.f;
+    }
     __syncthreads();                                          // stage 0 is in buffer A
     for (int s = 0; s < nstage; ++s) {
         const unsigned char* zs = (s & 1) ? zsB : zsA;
@@ -207,8 +216,14 @@ __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
             KCCOT_T4(m, m) KCCOT_T4(h, l) KCCOT_T4(l, h) KCCOT_T4(h, m) KCCOT_T4(m, h) KCCOT_T4(h, h)   // smallest terms first
 #undef KCCOT_T4
         }
+        if ((s % TFLUSH) == TFLUSH - 1) {
+            sum00 += acc00; sum01 += acc01; sum10 += acc10; sum11 += acc11;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+        }
         __syncthreads();                                      // stage s consumed; stage s + 1 is complete
     }
+    sum00 += acc00; sum01 += acc01; sum10 += acc10; sum11 += acc11;
 
     // accumulator register r of lane l is element ((r&3) + 8*(r>>2) + 4*(l>>5), l&31) of its 32 x 32 tile
     float* o = ta.part + ((int64_t)pair * ta.nchunk + chunk_id) * TELEMS;
@@ -216,10 +231,10 @@ __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = rowb + (r & 3) + 8 * (r >> 2);
-        o[row * TP + col] = acc00[r];
-        o[row * TP + col + 32] = acc01[r];
-        o[(row + 32) * TP + col] = acc10[r];
-        o[(row + 32) * TP + col + 32] = acc11[r];
+        o[row * TP + col] = sum00[r];
+        o[row * TP + col + 32] = sum01[r];
+        o[(row + 32) * TP + col] = sum10[r];
+        o[(row + 32) * TP + col + 32] = sum11[r];
     }
 }
 

@@ -506,6 +506,254 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_bwd_reg(SinkBwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused solve + reverse sweep of the mixed divergence (compute_sinkhorn_loss when a gradient is wanted):
+// ONE persistent launch per loss, one workgroup per problem, the whole dual history in LDS.
+//
+//   * the history row written by a half-step IS the exchange array the next half-step reads (row k of `hu` holds
+//     U_k, row 0 = zeros): one ds_write per line and half-step instead of an exchange write, a global history store
+//     and (shortcut build) a ring store; rows k-3 .. k are also the ring the exact periodic-state shortcut needs;
+//   * the reverse sweep starts the moment the final cost is known and reads U_t / V_t / V_{t-1} straight from LDS:
+//     no second launch, no reload of C (it is still in registers in both orientations), no 2*L*n-float history
+//     round trip through global memory, no prefetch / refill step inside the sweep;
+//   * d loss / d C3 is produced for dLoss = 1 with the weights {2,-1,-1} of gan_utils.py:225; the cost backward
+//     multiplies by the upstream scalar when it builds its coefficients (the gradient is linear in it).
+// Arithmetic is that of sinkhorn_fwd_body / sinkhorn_bwd_reg, instruction for instruction: costs, iteration counts and
+// duals are bit-identical to the two-kernel path, dC to the two-kernel path at the same lanes-per-line.
+// Eligibility (host): n <= 128 and 2 (L+1) NS floats of history within the CU's LDS; otherwise the two kernels run.
+// ------------------------------------------------------------------------------------------
+struct SinkFusedArgs {
+    const float* C;       // [3,n,n]
+    int n, L, Lmin;
+    float eps, inv_eps, thresh;
+    float* cost_out;      // [3]
+    int32_t* nits_out;    // [6]
+    float* loss_out;      // [1]
+    int* ticket;          // zero on entry, left zero
+    float* dC;            // [3,n,n]
+};
+
+template <int EPT, int LPR, bool SHORTCUT>
+__global__ __launch_bounds__(SK_MAXT) void sinkhorn_fused_reg(SinkFusedArgs a) {
+    constexpr int NS = EPT * LPR;                              // history row stride (>= n, a multiple of 4)
+    extern __shared__ __attribute__((aligned(16))) float hist[];
+    __shared__ __attribute__((aligned(16))) float gu[SK_MAXN + 16 * 16];
+    __shared__ __attribute__((aligned(16))) float gv[SK_MAXN + 16 * 16];
+    __shared__ float red[16];
+    __shared__ int mis[4];
+    const int p = blockIdx.x, n = a.n, L = a.L;
+    const int t = threadIdx.x, line = t / LPR, q = t % LPR;
+    const bool active = line < n;
+    const float* C = a.C + (int64_t)p * n * n;
+    const float k2 = a.inv_eps * LOG2E;
+    float* hu = hist;                                          // row k: U_k (k = 0 .. L), row 0 = 0
+    float* hv = hist + (size_t)(L + 1) * NS;
+
+    float crow[EPT], ccol[EPT];
+    load_costs<EPT, LPR>(C, n, line, q, k2, crow, ccol);
+    // row 0 and the pad columns [n, NS) of every row are zero (a pad dual pairs with c2 = +inf -> exp2(-inf) = 0)
+    for (int i = t; i < NS; i += blockDim.x) { hu[i] = 0.f; hv[i] = 0.f; }
+    if (NS > n) {
+        const int padw = NS - n;
+        for (int e = t; e < L * padw; e += blockDim.x) {
+            const int k = 1 + e / padw, i = n + e % padw;
+            hu[k * NS + i] = 0.f; hv[k * NS + i] = 0.f;
+        }
+    }
+    for (int i = t; i < SK_MAXN + 16 * 16; i += blockDim.x) { gu[i] = 0.f; gv[i] = 0.f; }
+    if (t < 4) mis[t] = 0;
+    __syncthreads();
+
+    const float lw2 = __builtin_amdgcn_logf(1.0f / (float)n);
+    const float err_scale = a.eps * LN2;
+    bool detect = SHORTCUT;
+    int computed = 0;
+    int mprev = ~0;
+    float pu2 = 0.f, pu3 = 0.f, pu4 = 0.f, pv2 = 0.f, pv3 = 0.f, pv4 = 0.f;
+    int nits = 0;
+    float ui = 0.f, vj = 0.f;
+    // ---------------------------------------------------------------- forward (see sinkhorn_fwd_body)
+    for (int it = 0; it < L; ++it) {
+        const float un = half_step<EPT, LPR, true>(crow, ui, hv + it * NS, q, lw2);
+        const float du = (active && q == 0) ? fabsf(un - ui) : 0.f;
+        int bits = 0;
+        if (SHORTCUT && detect) {
+            const unsigned b = __float_as_uint(un);
+            bits = (b != __float_as_uint(ui) ? 2 : 0) | (b != __float_as_uint(pu2) ? 4 : 0) |
+                   (b != __float_as_uint(pu3) ? 8 : 0) | (b != __float_as_uint(pu4) ? 16 : 0);
+            pu4 = pu3; pu3 = pu2; pu2 = ui;
+        }
+        ui = un;
+        if (active && q == 0) hu[(it + 1) * NS + line] = un;
+        lds_barrier();
+        const float vn = half_step<EPT, LPR, false>(ccol, vj, hu + (it + 1) * NS, q, lw2);
+        if (SHORTCUT && detect) {
+            const unsigned b = __float_as_uint(vn);
+            bits |= (b != __float_as_uint(vj) ? 2 : 0) | (b != __float_as_uint(pv2) ? 4 : 0) |
+                    (b != __float_as_uint(pv3) ? 8 : 0) | (b != __float_as_uint(pv4) ? 16 : 0);
+            pv4 = pv3; pv3 = pv2; pv2 = vj;
+            if (!active) bits = 0;
+            int wb = 0;
+#pragma unroll
+            for (int pp = 1; pp <= 4; ++pp)
+                if (__builtin_amdgcn_ballot_w64((bits >> pp) & 1)) wb |= 1 << pp;
+            if ((t & 63) == 0 && wb) atomicOr(&mis[it & 3], wb);
+        }
+        vj = vn;
+        if (active && q == 0) hv[(it + 1) * NS + line] = vn;
+        lds_barrier();
+        nits = it + 1;
+        ++computed;
+        if (nits >= a.Lmin && it + 1 < L) {                   // gan_utils.py:157-160
+            const float err = block_sum(du, red) * err_scale;
+            if (a.thresh > err) break;
+        }
+        if (SHORTCUT && detect) {
+            const int mcur = mis[it & 3];
+            if (t == 0) mis[(it + 2) & 3] = 0;
+            int per = 0;
+#pragma unroll
+            for (int pp = 4; pp >= 1; --pp)
+                if (it - 1 >= pp && !((mprev >> pp) & 1)) per = pp;
+            mprev = mcur;
+            if (per) {
+                detect = false;
+                int first_stop = a.Lmin < 1 ? 1 : a.Lmin;
+                const int K1 = (L < first_stop ? L : first_stop) - 1;
+                if (K1 > nits) {
+                    // states from S_{nits-per+1} on repeat with period per: row k <- row lo + (k - lo) mod per
+                    const int lo = nits - per + 1;
+                    for (int e = t; e < (K1 - nits) * n; e += blockDim.x) {
+                        const int k = nits + 1 + e / n, i = e % n;
+                        const int src = lo + (k - lo) % per;
+                        hu[k * NS + i] = hu[src * NS + i];
+                        hv[k * NS + i] = hv[src * NS + i];
+                    }
+                    __syncthreads();
+                    ui = hu[K1 * NS + (active ? line : 0)];
+                    vj = hv[K1 * NS + (active ? line : 0)];
+                    nits = K1;
+                    it = K1 - 1;
+                }
+            }
+        }
+    }
+
+    // gan_utils.py:162-164: pi = exp((-C + u + v^T)/eps); cost = sum(pi * C)
+    const float* Vn = hv + nits * NS;
+    const float* Un = hu + nits * NS;
+    float part = 0.f;
+    if (active) {
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const int idx = q * EPT + m;
+            if (idx < n) {
+                const float pi = __builtin_amdgcn_exp2f((ui - crow[m]) + Vn[idx]);
+                part += pi * C[(int64_t)line * n + idx];
+            }
+        }
+    }
+    const float cost = block_sum(part, red);
+    if (t == 0) {
+        a.cost_out[p] = cost;
+        a.nits_out[p] = nits;
+        a.nits_out[gridDim.x + p] = computed;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int tk = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == (int)gridDim.x - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float c0 = __hip_atomic_load(a.cost_out + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float c1 = __hip_atomic_load(a.cost_out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float c2 = __hip_atomic_load(a.cost_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.loss_out[0] = (2.0f * c0 - c1) - c2;
+            __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // ---------------------------------------------------------------- reverse sweep (see sinkhorn_bwd_reg)
+    const float g = (p == 0) ? 2.0f : -1.0f;                  // d(2 xy - xx - yy) at dLoss = 1
+    const int lsafe = active ? line : 0;
+    float drow[EPT], dcol[EPT];
+    {
+        const float uf = Un[lsafe], vf = Vn[lsafe];
+        float ov[EPT], ou[EPT];
+        load_other<EPT>(ov, Vn, q);
+        load_other<EPT>(ou, Un, q);
+        float su = 0.f, sv = 0.f;
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const bool ok = active && (q * EPT + m) < n;
+            const float cr = ok ? crow[m] : 0.f, cc = ok ? ccol[m] : 0.f;
+            const float pr = ok ? __builtin_amdgcn_exp2f((uf - cr) + ov[m]) : 0.f;
+            drow[m] = g * pr * (1.f - cr * LN2);
+            dcol[m] = 0.f;
+            su += pr * cr;
+            const float pc = ok ? __builtin_amdgcn_exp2f((ou[m] - cc) + vf) : 0.f;
+            sv += pc * cc;
+        }
+        su = seg_sum<LPR>(su);
+        sv = seg_sum<LPR>(sv);
+        if (active && q == 0) { gu[line] = g * su * LN2; gv[line] = g * sv * LN2; }
+    }
+    __syncthreads();
+    for (int it = nits; it >= 1; --it) {
+        const float* Uc = hu + it * NS;
+        const float* Vc = hv + it * NS;
+        const float* Vp = hv + (it - 1) * NS;
+        {   // (A) through v_t: row pass with Q_t
+            const float uu = Uc[lsafe] - lw2;
+            float ov[EPT], og[EPT];
+            load_other<EPT>(ov, Vc, q);
+            load_other<EPT>(og, gv, q);
+            float sa = 0.f;
+#pragma unroll
+            for (int m = 0; m < EPT; ++m) {
+                const float w = __builtin_amdgcn_exp2f((uu - crow[m]) + ov[m]) * og[m];
+                drow[m] += w;
+                sa += w;
+            }
+            sa = seg_sum<LPR>(sa);
+            if (active && q == 0) gu[line] = (it == nits ? gu[line] : 0.f) - sa;
+        }
+        lds_barrier();
+        {   // (B) through u_t: column pass with P_t
+            const float vv = Vp[lsafe] - lw2;
+            float ou[EPT], og[EPT];
+            load_other<EPT>(ou, Uc, q);
+            load_other<EPT>(og, gu, q);
+            float r = 0.f;
+#pragma unroll
+            for (int m = 0; m < EPT; ++m) {
+                const float w = __builtin_amdgcn_exp2f((ou[m] - ccol[m]) + vv) * og[m];
+                dcol[m] += w;
+                r += w;
+            }
+            r = seg_sum<LPR>(r);
+            if (active && q == 0) gv[line] = -r;
+        }
+        lds_barrier();
+    }
+    // dC = row-layout part + (column-layout part)^T
+    float* dC = a.dC + (int64_t)p * n * n;
+    if (active) {
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const int idx = q * EPT + m;
+            if (idx < n) dC[(int64_t)line * n + idx] = drow[m];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const int idx = q * EPT + m;
+            if (idx < n) dC[(int64_t)idx * n + line] += dcol[m];
+        }
+    }
+}
+
 // gan_utils.py:225: loss = 2.0 * loss_xy - loss_xx - loss_yy, evaluated left to right in fp32
 __global__ void mixed_divergence_fwd(const float* __restrict__ cost3, float* __restrict__ loss) {
     if (threadIdx.x == 0) loss[0] = (2.0f * cost3[0] - cost3[1]) - cost3[2];

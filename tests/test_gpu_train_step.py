@@ -1,10 +1,15 @@
 """GPU: the training-step API (kernel_train.py:219-292) end to end on a small configuration: PyTorch G/D + HIP loss
 path, both steps, all three kernel choices, and the fit / sample loop.
 
-Runs in the conservative convolution mode (every convolution, forward and backward, on the native ATen kernels):
-round 1 traced intermittent "Memory access fault by GPU" aborts of this loop to ONE MIOpen backward-data solver
-(kccotgan_amd/gan.py); the default mode switches that solver off and is exercised by
-tools/dbg_fit.py and tools/bench_train.py, the driver's test tier stays off MIOpen altogether."""
+The in-process tests run in the conservative convolution mode (every convolution, forward and backward, on the
+native ATen kernels): round 1 traced intermittent "Memory access fault by GPU" aborts of this loop to ONE MIOpen
+backward-data solver (kccotgan_amd/__init__.py).  The SHIPPED default (MIOpen with that solver
+switched off) is exercised by test_default_convolution_mode_in_a_child_process -- in a fresh child process, so that
+a device fault there fails that one test with a non-zero exit code instead of taking the tier down."""
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
@@ -60,3 +65,16 @@ def test_fit_loop_logs_samples_and_stops_on_non_finite_loss():
         p.data.fill_(float("nan"))
     out = tr.fit(ds.batches(videos, B, H, T, W, C), log=None)
     assert out["exploded"] and out["iterations"] == 1
+
+
+def test_default_convolution_mode_in_a_child_process():
+    """The shipped configuration (what `KCCOTTrainer` does when nobody touches the convolution mode) on round 1's
+    deterministic fault reproducer, once, in a fresh process (tests/train_default_mode_child.py).  MIOpen's fast
+    find keeps the solver search to seconds."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ("KCCOT_NATIVE_CONV", "MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC")}
+    env["MIOPEN_FIND_MODE"] = "2"
+    p = subprocess.run([sys.executable, os.path.join(here, "train_default_mode_child.py")], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, "child exit code %d\n%s\n%s" % (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    assert "done 6 False" in p.stdout, p.stdout[-1500:]
