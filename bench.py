@@ -150,7 +150,15 @@ def time_sinkhorn(C3, L=100, reps=50):
     b_us = time_launches(bwd, reps, 5)
     its = int(nits[:3].max())
     floor_us = 256.0 / (PEAK_CLOCK_GHZ * 1e3)
-    return {"n": n, "iterations": its, "fwd_us": f_us, "bwd_us": b_us,
+    fused = {}
+    if lib.kccot_sinkhorn_fused_eligible(n, L):
+        # what the loss path runs when a gradient is wanted: solves + reverse sweep in ONE launch, history in LDS
+        fu = lambda: check(lib.kccot_sinkhorn_divergence_fused_f32(ptr(C3), n, 1.0, L, 100, 1e-2, ptr(cost3), ptr(nits),
+                                                                   ptr(loss), ptr(ticket), ptr(dC3), st), "sk_fused")
+        fu_us = time_launches(fu, reps, 5)
+        fused = {"fused_fwd_bwd_us": fu_us, "fused_us_per_half_step": fu_us / (4 * its),
+                 "fused_over_floor": fu_us / (4 * its) / floor_us, "two_launch_fwd_plus_bwd_us": f_us + b_us}
+    return {"n": n, "iterations": its, "fwd_us": f_us, "bwd_us": b_us, **fused,
             "fwd_us_per_half_step": f_us / (2 * its), "bwd_us_per_half_step": b_us / (2 * its),
             "fwd_cycles_per_half_step_at_2.4GHz": f_us / (2 * its) * PEAK_CLOCK_GHZ * 1e3,
             "exp_issue_floor_cycles": 256, "exp_issue_floor_us_per_half_step": floor_us,

@@ -206,6 +206,33 @@ int kccot_sinkhorn_loss_bwd_f32(const float* gloss, const float* real, const flo
                                 float* dm_real, float* dm_fake, void* ws, size_t ws_bytes,
                                 kccot_stream_t stream);
 
+/* The same loss with the solves AND the reverse sweep in one persistent launch (the dual history stays in LDS; what
+ * tf.GradientTape replays through the unrolled loop, kernel_train.py:287-289, is computed before the kernel leaves
+ * the CU).  Eligible when n <= 128 and 2 (L+1) n floats of history fit the CU's LDS (kccot_sinkhorn_fused_eligible;
+ * configs[0] and configs[1] are).  dC3_unit [3,n,n] = d loss / d C3 at dLoss = 1; the backward multiplies by the
+ * upstream scalar `gloss` (one device float) while building its coefficients.  Costs, iteration counts and loss
+ * are bit-identical to the two-launch form.  KCCOT_SK_NO_FUSED=1 reports "not eligible". */
+int kccot_sinkhorn_fused_eligible(int n, int L);
+int kccot_sinkhorn_divergence_fused_f32(const float* C3, int n, float eps, int L, int Lmin, float thresh,
+                                        float* cost3_out, int32_t* nits_out, float* loss_out, int32_t* ticket,
+                                        float* dC3_unit, kccot_stream_t stream);
+int kccot_pairwise_cost3_bwd_scaled_f32(const float* g3, const float* gscale, const float* real, const float* fake,
+                                        int B, int64_t K, float sc, const float* h_fake, const float* h_real,
+                                        const float* m_real, const float* m_fake, int T, int J,
+                                        float* dfake, float* dh_fake, float* dh_real, float* dm_real,
+                                        float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream);
+int kccot_sinkhorn_loss_fused_fwd_f32(const float* real, const float* fake, int B, int64_t K, float sc,
+                                      const float* h_fake, const float* h_real, const float* m_real,
+                                      const float* m_fake, int T, int J, float eps, int L, int Lmin,
+                                      float thresh, unsigned flags, float* C3, float* dC3_unit,
+                                      float* cost3_out, int32_t* nits_out, float* loss_out, int32_t* ticket,
+                                      void* ws, size_t ws_bytes, kccot_stream_t stream);
+int kccot_sinkhorn_loss_fused_bwd_f32(const float* gloss, const float* dC3_unit, const float* real,
+                                      const float* fake, int B, int64_t K, float sc, const float* h_fake,
+                                      const float* h_real, const float* m_real, const float* m_fake, int T, int J,
+                                      float* dfake, float* dh_fake, float* dh_real, float* dm_real, float* dm_fake,
+                                      void* ws, size_t ws_bytes, kccot_stream_t stream);
+
 /* Mixed Sinkhorn divergence (gan_utils.py:225): loss = 2*cost3[0] - cost3[1] - cost3[2] for
  * cost3 = [W(real,fake), W(real,real), W(fake,fake)], and its backward gcost3 = gloss*[2,-1,-1].
  * All arguments are device pointers (one launch each, no host round trip). */

@@ -54,6 +54,14 @@ SIGNATURES = {
                                          _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "kccot_sinkhorn_loss_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _f, _i,
                                          _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_sinkhorn_fused_eligible": (_i, [_i, _i]),
+    "kccot_sinkhorn_divergence_fused_f32": (_i, [_fp, _i, _f, _i, _i, _f, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "kccot_pairwise_cost3_bwd_scaled_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i,
+                                                 _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_sinkhorn_loss_fused_fwd_f32": (_i, [_fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _f, _i, _i, _f, _u,
+                                               _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_sinkhorn_loss_fused_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i,
+                                               _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "kccot_mixed_divergence_fwd_f32": (_i, [_fp, _fp, _fp]),
     "kccot_mixed_divergence_bwd_f32": (_i, [_fp, _fp, _fp]),
     "kccot_martingale_fwd_f32": (_i, [_fp, _i, _i, _i, _f, _f, _fp, _fp]),

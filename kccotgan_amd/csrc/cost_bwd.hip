@@ -84,8 +84,12 @@ __device__ __forceinline__ void build_coeffs_body(int m, int mode, const float* 
     }
 }
 
+// gscale (optional, one device float): the upstream scalar dLoss/dloss when g holds d loss / d C at dLoss = 1
+// (fused solve + sweep): every output of this stage is linear in it, so it rides on scaling_coef.
 __global__ __launch_bounds__(256) void build_coeffs(int mode, const float* __restrict__ g, const float* __restrict__ g2,
-                                                    int Bx, int By, float sc, float* __restrict__ Wt) {
+                                                    int Bx, int By, float sc, float* __restrict__ Wt,
+                                                    const float* __restrict__ gscale = nullptr) {
+    if (gscale) sc *= gscale[0];
     build_coeffs_body(blockIdx.x, mode, g, g2, Bx, By, sc, Wt);
 }
 
@@ -198,7 +202,8 @@ __device__ __forceinline__ void causal_grads_body(const CausalGradBatch& cb, int
     if (aa < jb.Ba && k < TJ) jb.out[(int64_t)aa * TJ + k] = tot * sc;
 }
 
-__global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, int J, float sc) {
+__global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, int J, float sc, const float* __restrict__ gscale) {
+    if (gscale) sc *= gscale[0];
     causal_grads_body(cb, T, J, sc, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -207,7 +212,9 @@ __global__ __launch_bounds__(256) void causal_grads(CausalGradBatch cb, int T, i
 __global__ __launch_bounds__(256) void coeffs_and_causal_grads(int mode, const float* __restrict__ g,
                                                                const float* __restrict__ g2, int Bx, int By, float sc,
                                                                float* __restrict__ Wt, int nbuild, CausalGradBatch cb,
-                                                               int T, int J, int gx, int gy, unsigned short* __restrict__ W3) {
+                                                               int T, int J, int gx, int gy, unsigned short* __restrict__ W3,
+                                                               const float* __restrict__ gscale) {
+    if (gscale) sc *= gscale[0];
     if ((int)blockIdx.x < nbuild) {
         build_coeffs_body(blockIdx.x, mode, g, g2, Bx, By, sc, Wt, W3);
     } else {
@@ -216,12 +223,12 @@ __global__ __launch_bounds__(256) void coeffs_and_causal_grads(int mode, const f
     }
 }
 
-static int launch_causal_grads(CausalGradBatch& cb, int T, int J, float sc, hipStream_t st) {
+static int launch_causal_grads(CausalGradBatch& cb, int T, int J, float sc, hipStream_t st, const float* gscale = nullptr) {
     if (cb.njobs == 0) return 0;
     int maxa = 0;
     for (int i = 0; i < cb.njobs; ++i) if (cb.job[i].Ba > maxa) maxa = cb.job[i].Ba;
     dim3 grid((T * J + 15) / 16, (maxa + 15) / 16, cb.njobs);
-    hipLaunchKernelGGL(causal_grads, grid, dim3(256), 0, st, cb, T, J, sc);
+    hipLaunchKernelGGL(causal_grads, grid, dim3(256), 0, st, cb, T, J, sc, gscale);
     return launch_status("causal_grads");
 }
 
@@ -525,12 +532,12 @@ extern "C" size_t kccot_pairwise_cost3_bwd_workspace_bytes(int B, int64_t K) {
     return align_up((size_t)2 * B * B * sizeof(float), 256) + align_up((size_t)3 * B * 2 * B * sizeof(unsigned short), 256);
 }
 
-extern "C" int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* real, const float* fake, int B,
-                                                 int64_t K, float sc, const float* h_fake, const float* h_real,
-                                                 const float* m_real, const float* m_fake, int T, int J,
-                                                 int row_begin, int row_count,
-                                                 float* dfake, float* dh_fake, float* dh_real, float* dm_real,
-                                                 float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream) {
+static int cost3_bwd_rows_impl(const float* g3, const float* gscale, const float* real, const float* fake, int B,
+                               int64_t K, float sc, const float* h_fake, const float* h_real,
+                               const float* m_real, const float* m_fake, int T, int J,
+                               int row_begin, int row_count,
+                               float* dfake, float* dh_fake, float* dh_real, float* dm_real,
+                               float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream) {
     if (!g3 || !real || !fake) return fail(KCCOT_EINVAL, "pairwise_cost3_bwd: null pointer");
     if (row_begin < 0 || row_count <= 0 || row_begin + row_count > B)
         return fail(KCCOT_EINVAL, "pairwise_cost3_bwd: bad row range [%d, %d) of %d", row_begin, row_begin + row_count, B);
@@ -549,24 +556,45 @@ extern "C" int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* r
     if (dh_real) cg.job[cg.njobs++] = CausalGradJob{dh_real, CG_H, row_count, B, row_begin, B, {gxx, nullptr}, {m_real, nullptr}};
     if (dm_real) cg.job[cg.njobs++] = CausalGradJob{dm_real, CG_M, row_count, B, row_begin, B, {gxy, gxx}, {h_fake, h_real}};
     if (dm_fake) cg.job[cg.njobs++] = CausalGradJob{dm_fake, CG_M, row_count, B, row_begin, B, {gyy, nullptr}, {h_fake, nullptr}};
-    if (!dfake) return launch_causal_grads(cg, T, J, sc, st);
+    if (!dfake) return launch_causal_grads(cg, T, J, sc, st, gscale);
     const size_t need = kccot_pairwise_cost3_bwd_workspace_bytes(B, K);
     if (!ws || ws_bytes < need)
         return fail(KCCOT_EWORKSPACE, "pairwise_cost3_bwd: workspace %zu < required %zu", ws_bytes, need);
     float* Wt = static_cast<float*>(ws);
     unsigned short* W3 = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + align_up((size_t)2 * B * B * sizeof(float), 256));
     if (cg.njobs == 0) {
-        hipLaunchKernelGGL(build_coeffs, dim3(B), dim3(256), 0, st, (int)CO_LOSS3_DFAKE, gxy, gyy, B, B, sc, Wt);
+        hipLaunchKernelGGL(build_coeffs, dim3(B), dim3(256), 0, st, (int)CO_LOSS3_DFAKE, gxy, gyy, B, B, sc, Wt, gscale);
         if ((rc = launch_status("build_coeffs"))) return rc;
         hipLaunchKernelGGL(split_coeffs, dim3((2 * B * B + 255) / 256), dim3(256), 0, st, (const float*)Wt, B, 2 * B, B, W3);
         if ((rc = launch_status("split_coeffs"))) return rc;
     } else {
         const int gx = (T * J + 15) / 16, gy = (row_count + 15) / 16;
         hipLaunchKernelGGL(coeffs_and_causal_grads, dim3(B + gx * gy * cg.njobs), dim3(256), 0, st, (int)CO_LOSS3_DFAKE,
-                           gxy, gyy, B, B, sc, Wt, B, cg, T, J, gx, gy, W3);
+                           gxy, gyy, B, B, sc, Wt, B, cg, T, J, gx, gy, W3, gscale);
         if ((rc = launch_status("coeffs_and_causal_grads"))) return rc;
     }
     return launch_apply(Wt + row_begin, B, real, B, fake, B, row_count, K, dfake, st, W3 + (int64_t)row_begin * 2 * B, B, 2 * B);
+}
+
+extern "C" int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* real, const float* fake, int B,
+                                                 int64_t K, float sc, const float* h_fake, const float* h_real,
+                                                 const float* m_real, const float* m_fake, int T, int J,
+                                                 int row_begin, int row_count,
+                                                 float* dfake, float* dh_fake, float* dh_real, float* dm_real,
+                                                 float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream) {
+    return cost3_bwd_rows_impl(g3, nullptr, real, fake, B, K, sc, h_fake, h_real, m_real, m_fake, T, J, row_begin, row_count,
+                               dfake, dh_fake, dh_real, dm_real, dm_fake, ws, ws_bytes, stream);
+}
+
+// g3 = d loss / d C3 at dLoss = 1 (kccot_sinkhorn_divergence_fused_f32), gscale = ONE device float dLoss/dloss
+extern "C" int kccot_pairwise_cost3_bwd_scaled_f32(const float* g3, const float* gscale, const float* real, const float* fake,
+                                                   int B, int64_t K, float sc, const float* h_fake, const float* h_real,
+                                                   const float* m_real, const float* m_fake, int T, int J,
+                                                   float* dfake, float* dh_fake, float* dh_real, float* dm_real,
+                                                   float* dm_fake, void* ws, size_t ws_bytes, kccot_stream_t stream) {
+    if (!gscale) return fail(KCCOT_EINVAL, "pairwise_cost3_bwd_scaled: null gscale");
+    return cost3_bwd_rows_impl(g3, gscale, real, fake, B, K, sc, h_fake, h_real, m_real, m_fake, T, J, 0, B,
+                               dfake, dh_fake, dh_real, dm_real, dm_fake, ws, ws_bytes, stream);
 }
 
 extern "C" int kccot_pairwise_cost3_bwd_f32(const float* g3, const float* real, const float* fake, int B,
@@ -608,20 +636,20 @@ extern "C" int kccot_pairwise_cost_bwd_f32(const float* g, const float* x, const
     if (same) {
         if (dx) {
             hipLaunchKernelGGL(build_coeffs, dim3(Bx), dim3(256), 0, st, (int)CO_SAME, g,
-                               (const float*)nullptr, Bx, Bx, sc, W1);
+                               (const float*)nullptr, Bx, Bx, sc, W1, (const float*)nullptr);
             if ((rc = launch_status("build_coeffs"))) return rc;
             if ((rc = launch_apply(W1, Bx, x, Bx, x, 0, Bx, K, dx, st))) return rc;
         }
     } else {
         if (dx) {
             hipLaunchKernelGGL(build_coeffs, dim3(Bx), dim3(256), 0, st, (int)CO_DX, g,
-                               (const float*)nullptr, Bx, By, sc, W1);
+                               (const float*)nullptr, Bx, By, sc, W1, (const float*)nullptr);
             if ((rc = launch_status("build_coeffs"))) return rc;
             if ((rc = launch_apply(W1, Bx, x, Bx, y, By, Bx, K, dx, st))) return rc;
         }
         if (dy) {
             hipLaunchKernelGGL(build_coeffs, dim3(By), dim3(256), 0, st, (int)CO_DY, g,
-                               (const float*)nullptr, Bx, By, sc, W2);
+                               (const float*)nullptr, Bx, By, sc, W2, (const float*)nullptr);
             if ((rc = launch_status("build_coeffs"))) return rc;
             if ((rc = launch_apply(W2, By, x, Bx, y, By, By, K, dy, st))) return rc;
         }

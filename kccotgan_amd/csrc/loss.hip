@@ -65,3 +65,34 @@ extern "C" int kccot_sinkhorn_loss_bwd_f32(const float* gloss, const float* real
     return kccot_pairwise_cost3_bwd_f32(dC3, real, fake, B, K, sc, h_fake, h_real, m_real, m_fake, T, J, dfake, dh_fake,
                                         dh_real, dm_real, dm_fake, stage, stage_bytes, stream);
 }
+
+// ---- the same with the fused solve + sweep (kccot_sinkhorn_divergence_fused_f32) ----------------------------------
+// forward = cost assembly -> ONE launch (three solves, combination, reverse sweep at dLoss = 1): C3 is scratch for the
+// caller, dC3_unit [3,B,B] is what the backward needs; backward = coefficient build (x gloss) -> video gradient.
+extern "C" int kccot_sinkhorn_loss_fused_fwd_f32(const float* real, const float* fake, int B, int64_t K, float sc,
+                                                 const float* h_fake, const float* h_real, const float* m_real,
+                                                 const float* m_fake, int T, int J, float eps, int L, int Lmin,
+                                                 float thresh, unsigned flags, float* C3, float* dC3_unit,
+                                                 float* cost3_out, int32_t* nits_out, float* loss_out, int32_t* ticket,
+                                                 void* ws, size_t ws_bytes, kccot_stream_t stream) {
+    if (!C3 || !dC3_unit || !cost3_out || !nits_out || !loss_out || !ticket)
+        return fail(KCCOT_EINVAL, "sinkhorn_loss_fused_fwd: null output pointer");
+    if (ws_bytes < kccot_sinkhorn_loss_workspace_bytes(B, K) || (!ws && ws_bytes))
+        return fail(KCCOT_EWORKSPACE, "sinkhorn_loss_fused_fwd: workspace %zu < %zu bytes", ws_bytes,
+                    kccot_sinkhorn_loss_workspace_bytes(B, K));
+    int rc = kccot_pairwise_cost3_f32(real, fake, B, K, sc, h_fake, h_real, m_real, m_fake, T, J, flags, C3, ws, ws_bytes,
+                                      stream);
+    if (rc) return rc;
+    return kccot_sinkhorn_divergence_fused_f32(C3, B, eps, L, Lmin, thresh, cost3_out, nits_out, loss_out, ticket, dC3_unit,
+                                               stream);
+}
+
+extern "C" int kccot_sinkhorn_loss_fused_bwd_f32(const float* gloss, const float* dC3_unit, const float* real,
+                                                 const float* fake, int B, int64_t K, float sc, const float* h_fake,
+                                                 const float* h_real, const float* m_real, const float* m_fake, int T, int J,
+                                                 float* dfake, float* dh_fake, float* dh_real, float* dm_real, float* dm_fake,
+                                                 void* ws, size_t ws_bytes, kccot_stream_t stream) {
+    if (!gloss || !dC3_unit) return fail(KCCOT_EINVAL, "sinkhorn_loss_fused_bwd: null pointer");
+    return kccot_pairwise_cost3_bwd_scaled_f32(dC3_unit, gloss, real, fake, B, K, sc, h_fake, h_real, m_real, m_fake, T, J,
+                                               dfake, dh_fake, dh_real, dm_real, dm_fake, ws, ws_bytes, stream);
+}

@@ -912,6 +912,63 @@ extern "C" int kccot_mixed_divergence_bwd_f32(const float* gloss, float* gcost3_
     return launch_status("mixed_divergence_bwd");
 }
 
+// ---- fused solve + reverse sweep (sinkhorn_fused_reg) -------------------------------------------------
+static size_t fused_hist_bytes(int n, int L) {
+    const SinkGeom g = sink_geom(n, true);
+    return (size_t)2 * ((size_t)L + 1) * g.lpr * g.ept * sizeof(float);
+}
+
+extern "C" int kccot_sinkhorn_fused_eligible(int n, int L) {
+    const char* e = getenv("KCCOT_SK_NO_FUSED");          // =1: always the two-kernel path (A/B, equality tests)
+    if (e && atoi(e) == 1) return 0;
+    if (n <= 0 || n > SK_MAXN || L < 0) return 0;
+    return fused_hist_bytes(n, L) <= (size_t)144 * 1024;  // + ~4 KB of static LDS, inside the CU's 160 KB
+}
+
+template <int EPT, int LPR, bool SC>
+static int launch_fused(const SinkFusedArgs& a, size_t lds, hipStream_t st) {
+    static bool attr_set = false;                          // one per instantiation
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_fused_reg<EPT, LPR, SC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+            return fail(KCCOT_EUNSUPPORTED, "sinkhorn_fused: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sinkhorn_fused_reg<EPT, LPR, SC>), dim3(3), dim3((a.n * LPR + 63) / 64 * 64), lds, st, a);
+    return launch_status("sinkhorn_fused_reg");
+}
+
+template <bool SC>
+static int dispatch_fused(const SinkGeom& g, const SinkFusedArgs& a, size_t lds, hipStream_t st) {
+    if (g.lpr == 16) {
+        switch (g.ept) {
+            case 1: return launch_fused<1, 16, SC>(a, lds, st);
+            case 2: return launch_fused<2, 16, SC>(a, lds, st);
+            default: return launch_fused<4, 16, SC>(a, lds, st);
+        }
+    }
+    if (g.lpr == 4) return launch_fused<16, 4, SC>(a, lds, st);
+    return g.ept == 8 ? launch_fused<8, 8, SC>(a, lds, st) : launch_fused<16, 8, SC>(a, lds, st);
+}
+
+// The three solves of compute_sinkhorn_loss, their combination AND the reverse sweep in ONE launch:
+// dC3_unit [3,n,n] = d loss / d C3 at dLoss = 1.  No dual history leaves the CU.  `ticket` as above.
+extern "C" int kccot_sinkhorn_divergence_fused_f32(const float* C3, int n, float eps, int L, int Lmin, float thresh,
+                                                   float* cost3_out, int32_t* nits_out, float* loss_out, int32_t* ticket,
+                                                   float* dC3_unit, kccot_stream_t stream) {
+    if (!C3 || !cost3_out || !nits_out || !loss_out || !ticket || !dC3_unit)
+        return fail(KCCOT_EINVAL, "sinkhorn_divergence_fused: null pointer");
+    if (!(eps > 0.f)) return fail(KCCOT_EINVAL, "sinkhorn_divergence_fused: eps=%g", (double)eps);
+    if (!kccot_sinkhorn_fused_eligible(n, L))
+        return fail(KCCOT_EUNSUPPORTED, "sinkhorn_divergence_fused: n=%d L=%d does not fit (see kccot_sinkhorn_fused_eligible)", n, L);
+    const SinkGeom g = sink_geom(n, true);
+    SinkFusedArgs a{C3, n, L, Lmin, eps, (float)(1.0 / (double)eps), thresh, cost3_out, nits_out, loss_out,
+                    reinterpret_cast<int*>(ticket), dC3_unit};
+    const size_t lds = fused_hist_bytes(n, L);
+    hipStream_t st = (hipStream_t)stream;
+    return sink_shortcut_enabled() ? dispatch_fused<true>(g, a, lds, st) : dispatch_fused<false>(g, a, lds, st);
+}
+
 // Mixed Sinkhorn divergence in one launch each way (compute_sinkhorn_loss, gan_utils.py:221-225):
 // the three solves of C3 = [xy, xx, yy] plus loss = 2 xy - xx - yy, combined by the last workgroup
 // to finish.  `ticket` is ONE device int that must be zero on entry (the kernel leaves it zero).

@@ -272,28 +272,42 @@ class _SinkhornLoss(torch.autograd.Function):
         keep = any(ctx.needs_input_grad[1:6])
         Lh = max(int(L), 1)
         nc, nh = _pad64(3 * B * B), _pad64(3 * Lh * B)
-        state = _lib.empty((nc + (2 * nh if keep else 0),), torch.float32, dev)     # C3 | u_hist | v_hist
-        C3 = state[:nc]
-        uh, vh = (state[nc:nc + nh], state[nc + nh:]) if keep else (None, None)
         small = _lib.empty((4,), torch.float32, dev)                                 # cost3 | loss
         nits = _lib.empty((6,), torch.int32, dev)           # [reference-equivalent counts | iterations executed]
         ws, wsb = workspace(lib.kccot_sinkhorn_loss_workspace_bytes(B, K), real)
-        check(lib.kccot_sinkhorn_loss_fwd_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
-                                              ptr(m_fake), T, J, float(eps), int(L), int(Lmin), _THRESH, cost_flags,
-                                              ptr(C3), ptr(uh), ptr(vh), ptr(small), ptr(nits), ptr(small[3:]),
-                                              ptr(_ticket(dev)), ws, wsb, stream_of(real)), "sinkhorn_loss_fwd")
+        # With a gradient wanted and the dual history small enough for the CU's LDS (configs[0], configs[1]) the solves
+        # and the reverse sweep are ONE launch: no history leaves the CU, the state kept for backward is d loss / d C3
+        # at dLoss = 1 (12 B^2 bytes) and backward is coefficient build + video gradient only.
+        fused = bool(keep and lib.kccot_sinkhorn_fused_eligible(B, int(L)))
+        if fused:
+            state = _lib.empty((2 * nc,), torch.float32, dev)                        # C3 | dC3 at dLoss = 1
+            C3 = state[:nc]
+            check(lib.kccot_sinkhorn_loss_fused_fwd_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real),
+                                                        ptr(m_real), ptr(m_fake), T, J, float(eps), int(L), int(Lmin),
+                                                        _THRESH, cost_flags, ptr(C3), ptr(state[nc:]), ptr(small),
+                                                        ptr(nits), ptr(small[3:]), ptr(_ticket(dev)), ws, wsb,
+                                                        stream_of(real)), "sinkhorn_loss_fused_fwd")
+        else:
+            state = _lib.empty((nc + (2 * nh if keep else 0),), torch.float32, dev)  # C3 | u_hist | v_hist
+            C3 = state[:nc]
+            uh, vh = (state[nc:nc + nh], state[nc + nh:]) if keep else (None, None)
+            check(lib.kccot_sinkhorn_loss_fwd_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
+                                                  ptr(m_fake), T, J, float(eps), int(L), int(Lmin), _THRESH, cost_flags,
+                                                  ptr(C3), ptr(uh), ptr(vh), ptr(small), ptr(nits), ptr(small[3:]),
+                                                  ptr(_ticket(dev)), ws, wsb, stream_of(real)), "sinkhorn_loss_fwd")
         last_info[tag], last_info[tag + "_executed"] = nits[:3], nits[3:]
         last_info[tag + "_costs"] = small[:3]
         last_info[tag + "_C3"] = C3[:3 * B * B].view(3, B, B)
+        last_info[tag + "_fused_sweep"] = fused
         if keep:
             ctx.save_for_backward(real, fake, h_fake, h_real, m_real, m_fake, state, nits)
-        ctx.cfg = (float(sc), float(eps), Lh)
+        ctx.cfg = (float(sc), float(eps), Lh, fused)
         return small[3:].reshape(())
 
     @staticmethod
     def backward(ctx, g):
         real, fake, h_fake, h_real, m_real, m_fake, state, nits = ctx.saved_tensors
-        sc, eps, Lh = ctx.cfg
+        sc, eps, Lh, fused = ctx.cfg
         B, K = real.shape
         T, J = h_fake.shape[1], h_fake.shape[2]
         nc, nh = _pad64(3 * B * B), _pad64(3 * Lh * B)
@@ -303,10 +317,16 @@ class _SinkhornLoss(torch.autograd.Function):
         feats = _lib.empty((4, B, T, J), torch.float32, real.device) if any(need[2:6]) else None
         dhf, dhr, dmr, dmf = ((feats[i] if need[2 + i] else None) for i in range(4))
         ws, wsb = workspace(lib.kccot_sinkhorn_loss_workspace_bytes(B, K), real)
-        check(lib.kccot_sinkhorn_loss_bwd_f32(ptr(g), ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
-                                              ptr(m_fake), T, J, eps, Lh, ptr(state[:nc]), ptr(state[nc:nc + nh]),
-                                              ptr(state[nc + nh:]), ptr(nits), ptr(dfake), ptr(dhf), ptr(dhr), ptr(dmr),
-                                              ptr(dmf), ws, wsb, stream_of(real)), "sinkhorn_loss_bwd")
+        if fused:
+            check(lib.kccot_sinkhorn_loss_fused_bwd_f32(ptr(g), ptr(state[nc:]), ptr(real), ptr(fake), B, K, sc, ptr(h_fake),
+                                                        ptr(h_real), ptr(m_real), ptr(m_fake), T, J, ptr(dfake), ptr(dhf),
+                                                        ptr(dhr), ptr(dmr), ptr(dmf), ws, wsb, stream_of(real)),
+                  "sinkhorn_loss_fused_bwd")
+        else:
+            check(lib.kccot_sinkhorn_loss_bwd_f32(ptr(g), ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
+                                                  ptr(m_fake), T, J, eps, Lh, ptr(state[:nc]), ptr(state[nc:nc + nh]),
+                                                  ptr(state[nc + nh:]), ptr(nits), ptr(dfake), ptr(dhf), ptr(dhr), ptr(dmr),
+                                                  ptr(dmf), ws, wsb, stream_of(real)), "sinkhorn_loss_bwd")
         return None, dfake, dhf, dhr, dmr, dmf, None, None, None, None, None
 
 

@@ -881,6 +881,45 @@ def test_graphed_loss_is_bit_identical(G, L):
         np.testing.assert_array_equal(tt[k].grad.cpu().numpy(), -egrads[k].cpu().numpy())
 
 
+@pytest.mark.parametrize("shortcut", ["on", "off"])
+@pytest.mark.parametrize("shape,seed,regime", [("tiny", 0, "near"), ("small", 1, "far"), ("cfg1", 1, "far"), ("deci64", 0, "near"),
+                                               ("cfg2", 0, "near"), ("cfg2", 1, "far")])
+def test_fused_solve_and_sweep_equals_the_two_kernel_path(G, shape, seed, regime, shortcut, monkeypatch):
+    """compute_sinkhorn_loss with a gradient runs the three solves AND the reverse sweep as one persistent launch
+    with the dual history in LDS (sinkhorn_fused_reg) wherever that history fits; KCCOT_SK_NO_FUSED=1 restores the
+    forward kernel + global history + sweep kernel.  Same arithmetic instruction for instruction: loss, costs and
+    iteration counts are bit-identical, and so are all gradients when the two-kernel sweep runs at the same
+    lanes-per-line (KCCOT_SK_LPR=8 for 32 < n <= 64, where it otherwise uses 16).  A non-unit upstream gradient rides
+    on scaling_coef in the fused form (one extra rounding)."""
+    g, inp, _ = load(shape, seed, regime)
+    if shortcut == "off":
+        monkeypatch.setenv("KCCOT_SK_NO_SHORTCUT", "1")
+    wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]
+
+    def run(upstream):
+        t = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+        for k in wrt:
+            t[k].requires_grad_(True)
+        loss = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"], t["m_fake"])
+        grads = torch.autograd.grad(loss * upstream, [t[k] for k in wrt])
+        return (loss.detach().cpu().numpy(), G.last_info["compute_sinkhorn_loss"].tolist(),
+                G.last_info["compute_sinkhorn_loss_costs"].cpu().numpy(), bool(G.last_info["compute_sinkhorn_loss_fused_sweep"]),
+                [a.cpu().numpy() for a in grads])
+
+    fused = {u: run(u) for u in (1.0, -0.37)}
+    monkeypatch.setenv("KCCOT_SK_NO_FUSED", "1")
+    monkeypatch.setenv("KCCOT_SK_LPR", "8")
+    plain = {u: run(u) for u in (1.0, -0.37)}
+    assert fused[1.0][3] and not plain[1.0][3]
+    assert _same_bits(fused[1.0][0].reshape(1), plain[1.0][0].reshape(1)) and fused[1.0][1] == plain[1.0][1]
+    assert _same_bits(fused[1.0][2], plain[1.0][2])
+    assert rel(fused[1.0][0], g["loss"]) < 1e-4
+    for a, b in zip(fused[1.0][4], plain[1.0][4]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(fused[-0.37][4], plain[-0.37][4]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-6 * np.abs(b).max())
+
+
 # ---------------------------------------------------------------- size-independent properties at BASELINE full sizes
 FULL_SIZE = [((64, 64, 30, 64, 1), 100), ((128, 64, 30, 64, 3), 100),       # BASELINE configs[1], configs[2]
              ((256, 64, 30, 64, 3), 200), ((512, 128, 48, 128, 3), 300)]      # configs[3] (L = 200), configs[4] (L = 300)
