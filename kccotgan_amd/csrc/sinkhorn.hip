@@ -534,7 +534,7 @@ struct SinkFusedArgs {
 };
 
 template <int EPT, int LPR, bool SHORTCUT>
-__global__ __launch_bounds__(SK_MAXT) void sinkhorn_fused_reg(SinkFusedArgs a) {
+__global__ __launch_bounds__(LPR * SK_MAXN < SK_MAXT ? LPR * SK_MAXN : SK_MAXT) void sinkhorn_fused_reg(SinkFusedArgs a) {
     constexpr int NS = EPT * LPR;                              // history row stride (>= n, a multiple of 4)
     extern __shared__ __attribute__((aligned(16))) float hist[];
     __shared__ __attribute__((aligned(16))) float gu[SK_MAXN + 16 * 16];
@@ -697,19 +697,36 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fused_reg(SinkFusedArgs a) {
         if (active && q == 0) { gu[line] = g * su * LN2; gv[line] = g * sv * LN2; }
     }
     __syncthreads();
+    // The plans Q_t (pass A) and P_t (pass B) depend on the HISTORY only, not on the running gradients: the dependent
+    // chain of a half-step is gv -> 8 multiply-adds -> DPP sum -> gu.  Their exp2 are therefore evaluated one pass
+    // AHEAD, in the shadow of the LDS round trip that follows every barrier (ds_read of the gradients): the same
+    // instructions, issued while the wave would otherwise wait.
+    float qa[EPT], pb[EPT];
+    auto plan_a = [&](int it) {      // Q_it[line][q*EPT+m] = exp2((U_it,line - lw2 - c) + V_it,col)
+        const float uu = hu[it * NS + lsafe] - lw2;
+        float ov[EPT];
+        load_other<EPT>(ov, hv + it * NS, q);
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) qa[m] = __builtin_amdgcn_exp2f((uu - crow[m]) + ov[m]);
+    };
+    auto plan_b = [&](int it) {      // P_it[q*EPT+m][line] = exp2((U_it,row - c) + V_{it-1,line} - lw2)
+        const float vv = hv[(it - 1) * NS + lsafe] - lw2;
+        float ou[EPT];
+        load_other<EPT>(ou, hu + it * NS, q);
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) pb[m] = __builtin_amdgcn_exp2f((ou[m] - ccol[m]) + vv);
+    };
+    if (nits >= 1) plan_a(nits);
     for (int it = nits; it >= 1; --it) {
-        const float* Uc = hu + it * NS;
-        const float* Vc = hv + it * NS;
-        const float* Vp = hv + (it - 1) * NS;
         {   // (A) through v_t: row pass with Q_t
-            const float uu = Uc[lsafe] - lw2;
-            float ov[EPT], og[EPT];
-            load_other<EPT>(ov, Vc, q);
+            float og[EPT];
             load_other<EPT>(og, gv, q);
+            plan_b(it);
+            __builtin_amdgcn_sched_barrier(0);          // keep the exp2 of the next pass in the shadow of the gv read
             float sa = 0.f;
 #pragma unroll
             for (int m = 0; m < EPT; ++m) {
-                const float w = __builtin_amdgcn_exp2f((uu - crow[m]) + ov[m]) * og[m];
+                const float w = qa[m] * og[m];
                 drow[m] += w;
                 sa += w;
             }
@@ -718,14 +735,14 @@ __global__ __launch_bounds__(SK_MAXT) void sinkhorn_fused_reg(SinkFusedArgs a) {
         }
         lds_barrier();
         {   // (B) through u_t: column pass with P_t
-            const float vv = Vp[lsafe] - lw2;
-            float ou[EPT], og[EPT];
-            load_other<EPT>(ou, Uc, q);
+            float og[EPT];
             load_other<EPT>(og, gu, q);
+            if (it > 1) plan_a(it - 1);
+            __builtin_amdgcn_sched_barrier(0);
             float r = 0.f;
 #pragma unroll
             for (int m = 0; m < EPT; ++m) {
-                const float w = __builtin_amdgcn_exp2f((ou[m] - ccol[m]) + vv) * og[m];
+                const float w = pb[m] * og[m];
                 dcol[m] += w;
                 r += w;
             }

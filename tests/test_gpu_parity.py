@@ -823,9 +823,12 @@ def test_rbf_mmd_gradient_wrt_fake():
 
 
 # ---------------------------------------------------------------- one-call loss and graph capture
-def test_one_call_loss_equals_staged_path(G, L):
-    """kccot_sinkhorn_loss_{fwd,bwd}_f32 only sequence the stage entry points: bit-identical to
-    _Cost3 followed by _SinkhornDivergence, values and gradients."""
+def test_one_call_loss_equals_staged_path(G, L, monkeypatch):
+    """The one-call loss entry points (cost assembly + fused solve/sweep, or the two-kernel sequence where the history
+    does not fit LDS) against _Cost3 followed by _SinkhornDivergence: bit-identical values and gradients.  (The
+    staged reverse sweep is pinned to the fused kernel's 8 lanes per line for 32 < n <= 64, where it defaults to 16:
+    another summation order of the same terms otherwise.)"""
+    monkeypatch.setenv("KCCOT_SK_LPR", "8")
     for shape, seed, regime in (SMALL[0], ("cfg2", 1, "far")):
         g, inp, t = load(shape, seed, regime)
         wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]

@@ -25,3 +25,11 @@ def timeit(f, reps=200):
     return e0.elapsed_time(e1) / reps * 1e3
 tf = timeit(fwd); tb = timeit(bwd)
 print("%s: fwd %.1f us  bwd %.1f us  [counts | fwd executed] %s  cost %s" % (regime, tf, tb, nits.tolist(), [round(c, 4) for c in cost.tolist()]))
+if lib.kccot_sinkhorn_fused_eligible(n, L):
+    loss = torch.empty(1, device="cuda"); ticket = torch.zeros(1, dtype=torch.int32, device="cuda"); dCu = torch.empty_like(C)
+    def fused(): assert lib.kccot_sinkhorn_divergence_fused_f32(ptr(C), n, 1.0, L, 100, 1e-2, ptr(cost), ptr(nits), ptr(loss), ptr(ticket), ptr(dCu), None) == 0
+    tfu = timeit(fused)
+    bwd(); torch.cuda.synchronize()
+    print("%s: fused solve+sweep %.1f us (%.3f us per half-step over %d)  LPR=%s  max|dC_fused - dC_two_kernel| %.3g of %.3g" % (
+        regime, tfu, tfu / (4 * max(nits[3:].tolist())), 4 * max(nits[3:].tolist()), os.environ.get("KCCOT_SK_LPR", "default"),
+        float((dCu - dC).abs().max()), float(dC.abs().max())))
