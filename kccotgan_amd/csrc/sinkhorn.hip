@@ -20,6 +20,12 @@
 #include <math.h>
 #include <stdlib.h>
 
+// No floating-point contraction in this file: the solver kernels exist in several forms (forward / sweep / fused,
+// different lanes per line) that are tested for BIT-identical results, and a mul + add that the compiler fuses into
+// an fma in one form but not in another (it did, in the far regime, once the sweep's exp2 were hoisted) breaks that.
+// The reference's TensorFlow ops do not fuse either.
+#pragma clang fp contract(off)
+
 namespace kccot {
 
 constexpr int SK_MAXN = 128;      // register-resident kernels
