@@ -464,6 +464,131 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3(const unsigned short* __r
     }
 }
 
+// ---- large batches: 256 output rows per workgroup, the whole stack in one pass -------------------------------
+// apply_coeffs_x3 produces a 64-row output block from a 128-row stack chunk per launch; at B = 512 that is 8 x 8
+// launches, every stack chunk is fetched, split and staged again for each of the 8 row blocks, and the output is
+// read-modified-written 7 times (measured: 37 of the 64 ms of a configs[4] loss).  Here a workgroup owns 256 output
+// rows x 64 columns and walks ALL R = 2B stack rows in 128-row chunks: a staged chunk (exact 3-way split, same LDS
+// planes) now feeds 4 x as many MFMAs, the accumulators stay in registers (2 x 2 tiles per consumer wave), the
+// output is written once.  W does not fit registers any more (256 x R x 3 planes): the consumers stream their
+// fragments from L2 (the bf16 planes of W are <= 3 MB), three k-steps ahead of use.
+constexpr int AB_MT = 256;
+
+__global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short* __restrict__ W3, int Bt, int Rt,
+                                                            const float* __restrict__ src1, int n1,
+                                                            const float* __restrict__ src2, int n2, int64_t K,
+                                                            int64_t ntiles, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned char zs[2 * AX_BUF];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nchunk = (n1 + n2) / AM_ROWS;                   // 128-row chunks; n1 % 128 == 0 (host)
+    const int m0 = blockIdx.y * AB_MT;
+    if (wave < 4) {
+        // ---------------------------------------------------------------- producers (as apply_coeffs_x3)
+        const int c4 = (t & 15) * 4, rp0 = t >> 4;
+        float4 v[8];
+        auto load_stage = [&](int64_t tile, int c) {
+            const int g0 = c * AM_ROWS;
+            const float* base = g0 < n1 ? src1 + (int64_t)g0 * K : src2 + (int64_t)(g0 - n1) * K;
+            const int64_t col = tile * AM_COLS + c4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 2 * (rp0 + 16 * (j >> 1)) + (j & 1);
+                v[j] = (col + 4 <= K) ? *reinterpret_cast<const float4*>(base + (int64_t)r * K + col)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        int64_t tile = blockIdx.x;
+        int c = 0, buf = 0;
+        if (tile < ntiles) load_stage(tile, 0);
+        while (tile < ntiles) {
+            unsigned char* zb = zs + buf * AX_BUF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * (rp0 + 16 * i);
+                const float a[4] = {v[2 * i].x, v[2 * i].y, v[2 * i].z, v[2 * i].w};
+                const float b[4] = {v[2 * i + 1].x, v[2 * i + 1].y, v[2 * i + 1].z, v[2 * i + 1].w};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    unsigned ha, ma, la, hb, mb, lb;
+                    split3u(a[cc], ha, ma, la);
+                    split3u(b[cc], hb, mb, lb);
+                    const int off = (c4 + cc) * AX_COLP + r * 2;
+                    *reinterpret_cast<unsigned*>(zb + off) = __builtin_amdgcn_perm(hb, ha, 0x07060302u);
+                    *reinterpret_cast<unsigned*>(zb + AX_PLANE + off) = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
+                    *reinterpret_cast<unsigned*>(zb + 2 * AX_PLANE + off) = __builtin_amdgcn_perm(lb, la, 0x07060302u);
+                }
+            }
+            if (++c == nchunk) { c = 0; tile += gridDim.x; }
+            if (tile < ntiles) load_stage(tile, c);
+            buf ^= 1;
+            __syncthreads();
+        }
+        __syncthreads();          // the consumers' closing barrier
+        return;
+    }
+    // -------------------------------------------------------------------- consumers
+    const int w = wave - 4;                                   // rows m0 + 64 w .. + 63, all 64 columns
+    const int64_t plane = (int64_t)Bt * Rt;
+    const unsigned short* wb0 = W3 + (int64_t)(m0 + 64 * w + (lane & 31)) * Rt + 8 * (lane >> 5);
+    const unsigned short* wb1 = wb0 + (int64_t)32 * Rt;
+    const int nsteps = Rt >> 4;                               // k-steps per tile (a multiple of 8)
+    abf16x8 A[4][2][3];                                       // ring of fragment sets: step g lives in A[g & 3]
+    auto ldA = [&](int g, int slot) {
+        const int64_t o = (int64_t)16 * g;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            A[slot][0][pl] = *reinterpret_cast<const abf16x8*>(wb0 + pl * plane + o);
+            A[slot][1][pl] = *reinterpret_cast<const abf16x8*>(wb1 + pl * plane + o);
+        }
+    };
+    ldA(0, 0); ldA(1, 1); ldA(2, 2);
+    const int boff0 = (lane & 31) * AX_COLP + 16 * (lane >> 5), boff1 = boff0 + 32 * AX_COLP;
+    int buf = 0;
+    __syncthreads();                                          // the first stage is in buffer 0
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+        for (int c = 0; c < nchunk; ++c, buf ^= 1) {
+            const unsigned char* zb = zs + buf * AX_BUF;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                // fragments three steps ahead; past the end of this tile's walk they are the first steps of the next
+                int gn = c * 8 + s + 3;
+                if (gn >= nsteps) gn -= nsteps;
+                ldA(gn, (s + 3) & 3);
+                abf16x8 B0[3], B1[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint2* p0 = reinterpret_cast<uint2*>(&B0[pl]);
+                    uint2* p1 = reinterpret_cast<uint2*>(&B1[pl]);
+                    p0[0] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff0 + 32 * s);
+                    p0[1] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff0 + 32 * s + 8);
+                    p1[0] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff1 + 32 * s);
+                    p1[1] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff1 + 32 * s + 8);
+                }
+                // product-major order over the four accumulators (no MFMA waits on the one before it), smallest terms first
+#define KCCOT_A4(PA, PB)                                                                                   \
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][0][PA], B0[PB], acc00, 0, 0, 0);           \
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][0][PA], B1[PB], acc01, 0, 0, 0);           \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][1][PA], B0[PB], acc10, 0, 0, 0);           \
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][1][PA], B1[PB], acc11, 0, 0, 0);
+                KCCOT_A4(1, 1) KCCOT_A4(0, 2) KCCOT_A4(2, 0) KCCOT_A4(0, 1) KCCOT_A4(1, 0) KCCOT_A4(0, 0)
+#undef KCCOT_A4
+            }
+            __syncthreads();                                  // this stage is consumed; the next one is staged
+        }
+        const int64_t col = tile * AM_COLS + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + 64 * w + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (col < K) { out[m * K + col] = acc00[r]; out[(m + 32) * K + col] = acc10[r]; }
+            if (col + 32 < K) { out[m * K + col + 32] = acc01[r]; out[(m + 32) * K + col + 32] = acc11[r]; }
+        }
+    }
+}
+
 // Wt points at the first wanted output row's column; wpitch = full number of output rows of W
 // W3 (optional): the three bf16 planes of the SAME coefficients, [3][Bt][Rt] (split_coeffs), positioned at the first
 // wanted output row; selects the exact bf16 kernel when the stack is a multiple of 16 rows.
@@ -479,6 +604,13 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
         const int64_t ntiles = (K + AM_COLS - 1) / AM_COLS;
         const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);   // 2 workgroups per CU (VGPR-limited)
         const int R = n1 + n2;
+        // large batches: 256-row output tiles over the whole stack, one launch (KCCOT_APPLY_NO_M256=1: the block form)
+        if (x3 && Bout % AB_MT == 0 && n1 % AM_ROWS == 0 && n2 % AM_ROWS == 0 && R == Rt && !getenv("KCCOT_APPLY_NO_M256")) {
+            const unsigned gxb = (unsigned)(ntiles < 256 ? ntiles : 256);
+            hipLaunchKernelGGL(apply_coeffs_x3_m256, dim3(gxb, Bout / AB_MT), dim3(512), 0, st, W3, Bt, Rt, s1, n1, s2, n2, K,
+                               ntiles, out);
+            return launch_status("apply_coeffs_x3_m256");
+        }
         for (int ob = 0; ob < Bout; ob += 64) {
             const int bo = Bout - ob < 64 ? Bout - ob : 64;
             for (int r0 = 0; r0 < R; r0 += AM_ROWS) {
