@@ -944,7 +944,12 @@ static size_t fused_hist_bytes(int n, int L) {
 extern "C" int kccot_sinkhorn_fused_eligible(int n, int L) {
     const char* e = getenv("KCCOT_SK_NO_FUSED");          // =1: always the two-kernel path (A/B, equality tests)
     if (e && atoi(e) == 1) return 0;
-    if (n <= 0 || n > SK_MAXN || L < 0) return 0;
+    // n <= 64 by default: at 64 < n <= 128 (16 entries per lane and orientation) the fused kernel spills under the
+    // 128-VGPR cap of a 1024-thread workgroup and measured SLOWER than the two kernels at configs[2]
+    // (1.24 vs 1.08 ms per loss); KCCOT_SK_FUSED_MAXN=128 re-enables it for experiments.
+    const char* mx = getenv("KCCOT_SK_FUSED_MAXN");
+    const int maxn = mx ? atoi(mx) : 64;
+    if (n <= 0 || n > SK_MAXN || n > maxn || L < 0) return 0;
     return fused_hist_bytes(n, L) <= (size_t)144 * 1024;  // + ~4 KB of static LDS, inside the CU's 160 KB
 }
 

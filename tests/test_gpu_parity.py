@@ -919,8 +919,10 @@ def test_fused_solve_and_sweep_equals_the_two_kernel_path(G, shape, seed, regime
     assert rel(fused[1.0][0], g["loss"]) < 1e-4
     for a, b in zip(fused[1.0][4], plain[1.0][4]):
         np.testing.assert_array_equal(a, b)
+    # upstream != 1: the two-kernel sweep carries the factor from its first term on, the fused form multiplies at the
+    # end -- another rounding pattern of a cancelling sum (near regime), so the comparison is at the gradient floor
     for a, b in zip(fused[-0.37][4], plain[-0.37][4]):
-        np.testing.assert_allclose(a, b, rtol=0, atol=1e-6 * np.abs(b).max())
+        np.testing.assert_allclose(a, b, rtol=0, atol=GRAD_TOL_FLOOR * np.abs(b).max())
 
 
 # ---------------------------------------------------------------- size-independent properties at BASELINE full sizes
