@@ -552,30 +552,38 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
         for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
         for (int c = 0; c < nchunk; ++c, buf ^= 1) {
             const unsigned char* zb = zs + buf * AX_BUF;
+            abf16x8 Bf[2][2][3];                              // [step parity][column tile][piece]: one k-step ahead
+            auto ldB = [&](int st, int par) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint2* p0 = reinterpret_cast<uint2*>(&Bf[par][0][pl]);
+                    uint2* p1 = reinterpret_cast<uint2*>(&Bf[par][1][pl]);
+                    p0[0] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff0 + 32 * st);
+                    p0[1] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff0 + 32 * st + 8);
+                    p1[0] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff1 + 32 * st);
+                    p1[1] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff1 + 32 * st + 8);
+                }
+            };
+            ldB(0, 0);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                // fragments three steps ahead; past the end of this tile's walk they are the first steps of the next
+                // W fragments three k-steps ahead (past the end of this tile's walk: the first steps of the next tile),
+                // the staged tile's fragments one k-step ahead; the scheduling barrier keeps hipcc from sinking the loads
+                // back down to their first use (it did: L2 latency landed on every MFMA group)
                 int gn = c * 8 + s + 3;
                 if (gn >= nsteps) gn -= nsteps;
                 ldA(gn, (s + 3) & 3);
-                abf16x8 B0[3], B1[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    uint2* p0 = reinterpret_cast<uint2*>(&B0[pl]);
-                    uint2* p1 = reinterpret_cast<uint2*>(&B1[pl]);
-                    p0[0] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff0 + 32 * s);
-                    p0[1] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff0 + 32 * s + 8);
-                    p1[0] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff1 + 32 * s);
-                    p1[1] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff1 + 32 * s + 8);
-                }
+                if (s < 7) ldB(s + 1, (s + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
                 // product-major order over the four accumulators (no MFMA waits on the one before it), smallest terms first
-#define KCCOT_A4(PA, PB)                                                                                   \
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][0][PA], B0[PB], acc00, 0, 0, 0);           \
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][0][PA], B1[PB], acc01, 0, 0, 0);           \
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][1][PA], B0[PB], acc10, 0, 0, 0);           \
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][1][PA], B1[PB], acc11, 0, 0, 0);
+#define KCCOT_A4(PA, PB)                                                                                              \
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][0][PA], Bf[s & 1][0][PB], acc00, 0, 0, 0);            \
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][0][PA], Bf[s & 1][1][PB], acc01, 0, 0, 0);            \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][1][PA], Bf[s & 1][0][PB], acc10, 0, 0, 0);            \
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][1][PA], Bf[s & 1][1][PB], acc11, 0, 0, 0);
                 KCCOT_A4(1, 1) KCCOT_A4(0, 2) KCCOT_A4(2, 0) KCCOT_A4(0, 1) KCCOT_A4(1, 0) KCCOT_A4(0, 0)
 #undef KCCOT_A4
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                                  // this stage is consumed; the next one is staged
         }

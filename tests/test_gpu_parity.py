@@ -920,9 +920,11 @@ def test_fused_solve_and_sweep_equals_the_two_kernel_path(G, shape, seed, regime
     for a, b in zip(fused[1.0][4], plain[1.0][4]):
         np.testing.assert_array_equal(a, b)
     # upstream != 1: the two-kernel sweep carries the factor from its first term on, the fused form multiplies at the
-    # end -- another rounding pattern of a cancelling sum (near regime), so the comparison is at the gradient floor
-    for a, b in zip(fused[-0.37][4], plain[-0.37][4]):
-        np.testing.assert_allclose(a, b, rtol=0, atol=GRAD_TOL_FLOOR * np.abs(b).max())
+    # end -- another rounding pattern of a cancelling / ill-conditioned sum, so the comparison is at twice the
+    # gradient tolerance of the case (two fp32 evaluations, each within it of the fp64 value)
+    name = cases.case_name(shape, seed, regime)
+    for k, a, b in zip(wrt, fused[-0.37][4], plain[-0.37][4]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2 * grad_tol(name, k) * np.abs(b).max())
 
 
 # ---------------------------------------------------------------- size-independent properties at BASELINE full sizes

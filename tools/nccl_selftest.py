@@ -81,7 +81,8 @@ for sharded in (False, True):
     o3.backward(torch.ones_like(o3) * 0.5 + v)
     outs[sharded] = (o3.detach(), xv.grad)
 torch.cuda.synchronize()
-assert torch.equal(outs[True][0], outs[False][0])
+# (the sharded call runs the two-phase kernels, the plain one the streamed walk kernels: same taps, another fma order)
+assert float((outs[True][0] - outs[False][0]).abs().max()) <= 1e-6
 assert float((outs[True][1] - outs[False][1]).abs().max()) <= 2e-6 * float(outs[False][1].abs().max())
 print("nccl selftest ok: backend=%s loss=%.6f" % (dist.get_backend(), float(loss)))
 dist.destroy_process_group()
