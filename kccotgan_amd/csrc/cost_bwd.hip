@@ -474,6 +474,29 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3(const unsigned short* __r
 // fragments from L2 (the bf16 planes of W are <= 3 MB), three k-steps ahead of use.
 constexpr int AB_MT = 256;
 
+// W3 [3][Bt][Rt] (stack rows contiguous per output row) -> fragment-major tiles for apply_coeffs_x3_m256:
+//   Wt3[((pl * Bt/32 + m/32) * Rt/16 + r/16) * 512 + ((m % 32) + 32 * ((r % 16) / 8)) * 8 + r % 8]
+// i.e. the 64 x 16-byte MFMA A-fragment of (row tile, k-step) is ONE contiguous KiB.  In the row-major layout a
+// fragment load touches 64 different 128-byte lines and uses 32 bytes of each (measured: the W stream from L2 bound
+// the kernel -- 0.92 ms at B = 256 against 0.57 ms with the loads removed); tiled, every line is used whole.
+__global__ __launch_bounds__(256) void retile_coeffs(const unsigned short* __restrict__ W3, int Bt, int Rt,
+                                                     unsigned short* __restrict__ Wt3) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one 16-byte group (8 consecutive r) per thread
+    const int64_t ngroups = (int64_t)3 * Bt * (Rt / 8);
+    if (e >= ngroups) return;
+    const int rg = (int)(e % (Rt / 8));
+    const int m = (int)((e / (Rt / 8)) % Bt);
+    const int pl = (int)(e / ((int64_t)(Rt / 8) * Bt));
+    const int r = rg * 8;
+    const uint4 v = *reinterpret_cast<const uint4*>(W3 + ((int64_t)pl * Bt + m) * Rt + r);
+    const int64_t dst = ((((int64_t)pl * (Bt / 32) + m / 32) * (Rt / 16) + r / 16) * 64 + (m % 32) + 32 * ((r % 16) / 8)) * 8;
+    *reinterpret_cast<uint4*>(Wt3 + dst) = v;
+}
+
+// DIAG (diagnostic builds of the SAME kernel, selected by KCCOT_APPLY_DIAG, results are then WRONG -- timing only):
+// bit 0: the consumers read the staged fragments once per chunk instead of once per k-step; bit 1: they load their W
+// fragments once per tile; bit 2: the producers skip the split and the LDS writes.
+template <int DIAG>
 __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short* __restrict__ W3, int Bt, int Rt,
                                                             const float* __restrict__ src1, int n1,
                                                             const float* __restrict__ src2, int n2, int64_t K,
@@ -505,6 +528,7 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
             unsigned char* zb = zs + buf * AX_BUF;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (DIAG & 4) { if (v[2 * i].x == 123456.f) zb[0] = 1; continue; }
                 const int r = 2 * (rp0 + 16 * i);
                 const float a[4] = {v[2 * i].x, v[2 * i].y, v[2 * i].z, v[2 * i].w};
                 const float b[4] = {v[2 * i + 1].x, v[2 * i + 1].y, v[2 * i + 1].z, v[2 * i + 1].w};
@@ -529,13 +553,14 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
     }
     // -------------------------------------------------------------------- consumers
     const int w = wave - 4;                                   // rows m0 + 64 w .. + 63, all 64 columns
-    const int64_t plane = (int64_t)Bt * Rt;
-    const unsigned short* wb0 = W3 + (int64_t)(m0 + 64 * w + (lane & 31)) * Rt + 8 * (lane >> 5);
-    const unsigned short* wb1 = wb0 + (int64_t)32 * Rt;
     const int nsteps = Rt >> 4;                               // k-steps per tile (a multiple of 8)
+    // W3 is the fragment-major copy (retile_coeffs): row tile mt, k-step g -> 1 KiB at ((pl*Bt/32 + mt)*nsteps + g)*512
+    const int64_t plane = (int64_t)Bt * Rt;
+    const unsigned short* wb0 = W3 + (int64_t)((m0 + 64 * w) / 32) * nsteps * 512 + lane * 8;
+    const unsigned short* wb1 = wb0 + (int64_t)nsteps * 512;
     abf16x8 A[4][2][3];                                       // ring of fragment sets: step g lives in A[g & 3]
     auto ldA = [&](int g, int slot) {
-        const int64_t o = (int64_t)16 * g;
+        const int64_t o = (int64_t)512 * g;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             A[slot][0][pl] = *reinterpret_cast<const abf16x8*>(wb0 + pl * plane + o);
@@ -572,15 +597,15 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
                 // back down to their first use (it did: L2 latency landed on every MFMA group)
                 int gn = c * 8 + s + 3;
                 if (gn >= nsteps) gn -= nsteps;
-                ldA(gn, (s + 3) & 3);
-                if (s < 7) ldB(s + 1, (s + 1) & 1);
+                if (!(DIAG & 2)) ldA(gn, (s + 3) & 3);
+                if (s < 7 && !(DIAG & 1)) ldB(s + 1, (s + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // product-major order over the four accumulators (no MFMA waits on the one before it), smallest terms first
 #define KCCOT_A4(PA, PB)                                                                                              \
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][0][PA], Bf[s & 1][0][PB], acc00, 0, 0, 0);            \
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][0][PA], Bf[s & 1][1][PB], acc01, 0, 0, 0);            \
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][1][PA], Bf[s & 1][0][PB], acc10, 0, 0, 0);            \
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][1][PA], Bf[s & 1][1][PB], acc11, 0, 0, 0);
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(DIAG & 2) ? 0 : (s & 3)][0][PA], Bf[(DIAG & 1) ? 0 : (s & 1)][0][PB], acc00, 0, 0, 0); \
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(DIAG & 2) ? 0 : (s & 3)][0][PA], Bf[(DIAG & 1) ? 0 : (s & 1)][1][PB], acc01, 0, 0, 0); \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(DIAG & 2) ? 0 : (s & 3)][1][PA], Bf[(DIAG & 1) ? 0 : (s & 1)][0][PB], acc10, 0, 0, 0); \
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(DIAG & 2) ? 0 : (s & 3)][1][PA], Bf[(DIAG & 1) ? 0 : (s & 1)][1][PB], acc11, 0, 0, 0);
                 KCCOT_A4(1, 1) KCCOT_A4(0, 2) KCCOT_A4(2, 0) KCCOT_A4(0, 1) KCCOT_A4(1, 0) KCCOT_A4(0, 0)
 #undef KCCOT_A4
                 __builtin_amdgcn_sched_barrier(0);
@@ -601,7 +626,8 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
 // W3 (optional): the three bf16 planes of the SAME coefficients, [3][Bt][Rt] (split_coeffs), positioned at the first
 // wanted output row; selects the exact bf16 kernel when the stack is a multiple of 16 rows.
 static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, const float* s2, int n2, int Bout,
-                        int64_t K, float* out, hipStream_t st, const unsigned short* W3 = nullptr, int Bt = 0, int Rt = 0) {
+                        int64_t K, float* out, hipStream_t st, const unsigned short* W3 = nullptr, int Bt = 0, int Rt = 0,
+                        const unsigned short* W3base = nullptr, unsigned short* Wt3 = nullptr) {
     const bool al = (K % 4 == 0) && ((uintptr_t)s1 % 16 == 0) && (n2 == 0 || (uintptr_t)s2 % 16 == 0);
     const char* f32env = getenv("KCCOT_APPLY_F32");           // =1: the f32-input MFMA kernel (A/B and parity runs)
     const bool x3 = al && W3 && (n1 + n2) % 16 == 0 && Rt % 8 == 0 && ((uintptr_t)W3 % 16 == 0) && !(f32env && atoi(f32env) == 1);
@@ -613,10 +639,25 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
         const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);   // 2 workgroups per CU (VGPR-limited)
         const int R = n1 + n2;
         // large batches: 256-row output tiles over the whole stack, one launch (KCCOT_APPLY_NO_M256=1: the block form)
-        if (x3 && Bout % AB_MT == 0 && n1 % AM_ROWS == 0 && n2 % AM_ROWS == 0 && R == Rt && !getenv("KCCOT_APPLY_NO_M256")) {
+        if (x3 && Wt3 && Bout % AB_MT == 0 && Bt % 32 == 0 && n1 % AM_ROWS == 0 && n2 % AM_ROWS == 0 && R == Rt &&
+            !getenv("KCCOT_APPLY_NO_M256")) {
             const unsigned gxb = (unsigned)(ntiles < 256 ? ntiles : 256);
-            hipLaunchKernelGGL(apply_coeffs_x3_m256, dim3(gxb, Bout / AB_MT), dim3(512), 0, st, W3, Bt, Rt, s1, n1, s2, n2, K,
-                               ntiles, out);
+            // W3 is positioned at the first wanted output row (a multiple of 256 here): retile from the plane base
+            const int64_t row0 = (W3 - W3base) / Rt;
+            const int64_t ngroups = (int64_t)3 * Bt * (Rt / 8);
+            hipLaunchKernelGGL(retile_coeffs, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, W3base, Bt, Rt, Wt3);
+            int rct = launch_status("retile_coeffs");
+            if (rct) return rct;
+            const unsigned short* Wuse = Wt3 + (row0 / 32) * (int64_t)(Rt / 16) * 512;
+            (void)Wuse;
+            const char* dg = getenv("KCCOT_APPLY_DIAG");      // timing experiments only (wrong results), see the kernel
+            const int diag = dg ? atoi(dg) : 0;
+#define KCCOT_M256(D) hipLaunchKernelGGL(apply_coeffs_x3_m256<D>, dim3(gxb, Bout / AB_MT), dim3(512), 0, st, Wuse, Bt, Rt, s1, n1, s2, n2, K, ntiles, out)
+            switch (diag) {
+                case 1: KCCOT_M256(1); break; case 2: KCCOT_M256(2); break; case 3: KCCOT_M256(3); break;
+                case 4: KCCOT_M256(4); break; case 7: KCCOT_M256(7); break; default: KCCOT_M256(0); break;
+            }
+#undef KCCOT_M256
             return launch_status("apply_coeffs_x3_m256");
         }
         for (int ob = 0; ob < Bout; ob += 64) {
@@ -668,8 +709,8 @@ using namespace kccot;
 extern "C" size_t kccot_pairwise_cost3_bwd_workspace_bytes(int B, int64_t K) {
     (void)K;
     if (B <= 0) return 0;
-    // W [2B][B] f32, then its three bf16 planes [3][B][2B]
-    return align_up((size_t)2 * B * B * sizeof(float), 256) + align_up((size_t)3 * B * 2 * B * sizeof(unsigned short), 256);
+    // W [2B][B] f32, then its three bf16 planes [3][B][2B], then (B % 256 == 0) their fragment-major copy
+    return align_up((size_t)2 * B * B * sizeof(float), 256) + 2 * align_up((size_t)3 * B * 2 * B * sizeof(unsigned short), 256);
 }
 
 static int cost3_bwd_rows_impl(const float* g3, const float* gscale, const float* real, const float* fake, int B,
@@ -713,7 +754,9 @@ static int cost3_bwd_rows_impl(const float* g3, const float* gscale, const float
                            gxy, gyy, B, B, sc, Wt, B, cg, T, J, gx, gy, W3, gscale);
         if ((rc = launch_status("coeffs_and_causal_grads"))) return rc;
     }
-    return launch_apply(Wt + row_begin, B, real, B, fake, B, row_count, K, dfake, st, W3 + (int64_t)row_begin * 2 * B, B, 2 * B);
+    unsigned short* Wt3 = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(W3) + align_up((size_t)3 * B * 2 * B * sizeof(unsigned short), 256));
+    return launch_apply(Wt + row_begin, B, real, B, fake, B, row_count, K, dfake, st, W3 + (int64_t)row_begin * 2 * B, B, 2 * B,
+                        W3, (B % AB_MT == 0 && row_begin % AB_MT == 0) ? Wt3 : nullptr);
 }
 
 extern "C" int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* real, const float* fake, int B,

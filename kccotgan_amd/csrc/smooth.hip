@@ -680,7 +680,11 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
     const bool r34 = radius == 3 || radius == 4;
     float* one = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)n * sizeof(float), 256) +
                                           2 * align_up((size_t)nb * sizeof(float), 256));   // scalar slots: {1, 0, 0}
-    if (r34 && !nodiv && !getenv("KCCOT_SMOOTH_NO_STREAM") && (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W))) {
+    // (NO_DIVIDE runs here too, since round 2: both phases of the batch-sharded protocol -- local maximum, then the
+    // division by the all-reduced one -- must evaluate s with the SAME kernels, or the arg-max element comes out as
+    // 0.99999994 instead of exactly 1 and the adjoint's `out == 1` tie detection finds nothing: found by the RCCL
+    // world-size-1 test, where phase 1 took the per-axis chain and phase 2 the streamed walks)
+    if (r34 && !getenv("KCCOT_SMOOTH_NO_STREAM") && (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W))) {
         const int64_t WC = (int64_t)W * C;
         const bool three = axes != KCCOT_SMOOTH_T;
         // the last stage runs twice (maxima, then recompute + write s / max); earlier stages write raw sums
@@ -719,7 +723,7 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
                 if ((rc = launch_status("reduce_blockmax"))) return rc;
             }
             wa.out = out; wa.blockmax = nullptr; wa.mx = max_inout;
-            return launch_walk(WALK_WRITE, wa, radius, n, last, st);
+            return launch_walk(nodiv ? WALK_RAW : WALK_WRITE, wa, radius, n, last, st);   // NO_DIVIDE: the raw sums
         }
     }
     if (plane_eligible(T, W, C, radius, na) && !nodiv) {

@@ -104,3 +104,35 @@ def test_hip_smoothing_legacy_path_matches_reference_fixtures(name, monkeypatch)
     x = torch.from_numpy(v).cuda()
     np.testing.assert_allclose(ks.temporal_convolution(x, sigma).cpu().numpy(), g["temporal"], rtol=0, atol=ATOL_T)
     np.testing.assert_allclose(ks.gaussian_convolution3D(x, sigma).cpu().numpy(), g["conv3d"], rtol=0, atol=ATOL_3D)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c1_r3_s5", "c3_r3_s1p3", "cfg1frame"])
+def test_two_phase_protocol_of_the_sharded_smoothing_hits_exactly_one(name):
+    """The batch-sharded caller runs the forward in two phases -- KCCOT_SMOOTH_NO_DIVIDE (raw sums + local maximum),
+    all-reduce(MAX), KCCOT_SMOOTH_EXTERNAL_MAX (divide) -- and the adjoint finds the arg-max through `out == 1`
+    (the reference's reduce_max gradient, data_utils.py:520,573,581).  Both phases must therefore evaluate the sums
+    with the same kernels: the maximum of the result is EXACTLY 1 and the result equals the one-call form bit for
+    bit.  (Round 2 regression: phase 1 ran the per-axis chain, phase 2 the streamed walks, the maximum came out one
+    ulp below 1 and the sharded adjoint silently lost its arg-max term.)"""
+    import torch
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, ptr, check, workspace, stream_of
+    g, v, tk, sk, sigma = load(name)
+    x = torch.from_numpy(v).cuda()
+    B, H, T, W, C = x.shape
+    ws, wsb = workspace(lib.kccot_smooth_workspace_bytes(B, H, T, W, C), x)
+    for axes, radius, key in ((_lib.SMOOTH_T, tk // 2, "temporal"), (_lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W, sk // 2, "conv3d")):
+        one = torch.empty_like(x); two = torch.empty_like(x)
+        m1 = torch.empty(1, device=x.device); m2 = torch.empty(1, device=x.device)
+        check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, sigma, radius, axes, ptr(one), ptr(m1), ws, wsb, stream_of(x)), "one call")
+        check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, sigma, radius, axes | _lib.SMOOTH_NO_DIVIDE, ptr(two), ptr(m2), ws, wsb,
+                                       stream_of(x)), "phase 1")
+        raw_max = float(two.max())
+        assert raw_max == float(m2), (raw_max, float(m2))          # phase 1 leaves the raw sums and their maximum
+        check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, sigma, radius, axes | _lib.SMOOTH_EXTERNAL_MAX, ptr(two), ptr(m2), ws, wsb,
+                                       stream_of(x)), "phase 2")
+        torch.cuda.synchronize()
+        assert float(m1) == float(m2) and float(two.max()) == 1.0
+        assert torch.equal(one, two)
+        np.testing.assert_allclose(two.cpu().numpy(), g[key], rtol=0, atol=ATOL_3D)
