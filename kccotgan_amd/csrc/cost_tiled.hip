@@ -37,7 +37,53 @@ struct TileArgs {
     int B, nt, nchunk;
     int64_t K, chunk;
     float* part;      // [npairs][nchunk][TELEMS]
+    const unsigned short* planes;   // PLANES build: pre-split stack [3][2B][K] bf16 (presplit_stack), else null
 };
+
+// ---- one-time exact three-way split of the stack [real ; fake - real] into bf16 planes (round 2) ---------------------
+// gram_tile_x3's producers fetched, subtracted, split and staged every panel chunk once per PAIR it takes part in
+// (B = 512: 9 times), and the SQ counters showed the kernel parked on them (59 % of all wave cycles in s_waitcnt /
+// barrier, 27 % matrix-pipe utilisation at B = 512).  Memory is plentiful (288 GB): the stack is cut ONCE into its three
+// planes P[pl][row][k] (6 bytes per element: 14.5 GB at configs[4], 1.1 GB at configs[3]) and the Gram kernel's
+// producers become plain 16-byte copies.  Same pieces bit for bit (tsplit3_store's arithmetic), same MFMAs: identical sums.
+__global__ __launch_bounds__(256) void presplit_stack(const float* __restrict__ real, const float* __restrict__ fake, int B,
+                                                      int64_t K, unsigned short* __restrict__ planes) {
+    const int64_t groups_per_row = K >> 3;                       // 8 consecutive k per thread (K % 8 == 0)
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)2 * B * groups_per_row) return;
+    const int64_t row = e / groups_per_row, k = (e - row * groups_per_row) << 3;
+    float v[8];
+    if (row < B) {
+        const float4 a = *reinterpret_cast<const float4*>(real + row * K + k), b = *reinterpret_cast<const float4*>(real + row * K + k + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const int64_t o = (row - B) * K + k;
+        const float4 a = *reinterpret_cast<const float4*>(fake + o), b = *reinterpret_cast<const float4*>(fake + o + 4);
+        const float4 c = *reinterpret_cast<const float4*>(real + o), d = *reinterpret_cast<const float4*>(real + o + 4);
+        v[0] = a.x - c.x; v[1] = a.y - c.y; v[2] = a.z - c.z; v[3] = a.w - c.w;
+        v[4] = b.x - d.x; v[5] = b.y - d.y; v[6] = b.z - d.z; v[7] = b.w - d.w;
+    }
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned x = __float_as_uint(v[i]);
+        const float hf = __uint_as_float(x & 0xFFFF0000u);
+        const float r1 = v[i] - hf;                                            // exact
+        const float mm = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+        h[i] = x; m[i] = __float_as_uint(r1); l[i] = __float_as_uint(r1 - mm);     // pieces = the upper 16 bits of each word
+    }
+    const int64_t plane = (int64_t)2 * B * K, o = row * K + k;
+    uint4 ph, pm, pl;
+    ph.x = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u); ph.y = __builtin_amdgcn_perm(h[3], h[2], 0x07060302u);
+    ph.z = __builtin_amdgcn_perm(h[5], h[4], 0x07060302u); ph.w = __builtin_amdgcn_perm(h[7], h[6], 0x07060302u);
+    pm.x = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); pm.y = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+    pm.z = __builtin_amdgcn_perm(m[5], m[4], 0x07060302u); pm.w = __builtin_amdgcn_perm(m[7], m[6], 0x07060302u);
+    pl.x = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u); pl.y = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+    pl.z = __builtin_amdgcn_perm(l[5], l[4], 0x07060302u); pl.w = __builtin_amdgcn_perm(l[7], l[6], 0x07060302u);
+    *reinterpret_cast<uint4*>(planes + o) = ph;
+    *reinterpret_cast<uint4*>(planes + plane + o) = pm;
+    *reinterpret_cast<uint4*>(planes + 2 * plane + o) = pl;
+}
 
 __device__ __forceinline__ float4 tld4(const float* __restrict__ row, int64_t k, int64_t kend) {
     // K % 4 == 0 and 16-byte aligned rows (checked on the host); a stage may run past the chunk end
@@ -101,6 +147,7 @@ __device__ __forceinline__ void panel_rows(const TileArgs& a, int p, const float
 // consumer wave share each SIMD, whose VALU and matrix pipe run concurrently.  One barrier per 32-k stage.
 // (The first version did both roles in every wave with one wave per SIMD: the split sat between the MFMA phases
 // and B = 512 ran slower than the blocked path.)
+template <bool PLANES>
 __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
     __shared__ __attribute__((aligned(16))) unsigned char zsA[TBUF];
     __shared__ __attribute__((aligned(16))) unsigned char zsB[TBUF];
@@ -122,8 +169,57 @@ __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
     if (kbeg >= kend) return;
     const int nstage = (int)((kend - kbeg + TK - 1) / TK);
 
+    if (PLANES && wave < 4) {
+        // ------------------------------------------------------------------ producers, pre-split planes: pure copies.
+        // thread: rows r0 and r0 + 64 of each panel, the 8 k at c8 of the 32-k stage, all three planes
+        const int r0 = t >> 2, c8 = (t & 3) * 8;
+        const int64_t plane = (int64_t)2 * ta.B * K;
+        const unsigned short* pA = ta.planes + ((int64_t)pa * TP + r0) * K + c8;
+        const unsigned short* pB = ta.planes + ((int64_t)pb * TP + r0) * K + c8;
+        const int wbase = r0 * TPITCH + c8 * 2;
+        struct StageP { uint4 a[2][3], b[2][3]; };
+        StageP s0, s1;
+        auto ld = [&](const unsigned short* q, int64_t k0) {
+            return (k0 + c8 + 8 <= kend) ? *reinterpret_cast<const uint4*>(q + k0) : make_uint4(0u, 0u, 0u, 0u);
+        };
+        auto load_stage = [&](StageP& g, int64_t k0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    g.a[j][pl] = ld(pA + pl * plane + (int64_t)j * 64 * K, k0);
+                    if (!same) g.b[j][pl] = ld(pB + pl * plane + (int64_t)j * 64 * K, k0);
+                }
+        };
+        auto store_stage = [&](const StageP& g, unsigned char* zb) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    *reinterpret_cast<uint4*>(zb + pl * TPLANE + wbase + 64 * j * TPITCH) = g.a[j][pl];
+                    if (!same) *reinterpret_cast<uint4*>(zb + pl * TPLANE + wbase + (TP + 64 * j) * TPITCH) = g.b[j][pl];
+                }
+        };
+        load_stage(s0, kbeg);
+        if (nstage > 1) load_stage(s1, kbeg + TK);
+        for (int s = 0; s <= nstage; s += 2) {
+            if (s < nstage) {
+                store_stage(s0, zsA);
+                if (s + 2 < nstage) load_stage(s0, kbeg + (int64_t)(s + 2) * TK);
+            }
+            __syncthreads();
+            if (s + 1 <= nstage) {
+                if (s + 1 < nstage) {
+                    store_stage(s1, zsB);
+                    if (s + 3 < nstage) load_stage(s1, kbeg + (int64_t)(s + 3) * TK);
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
     if (wave < 4) {
-        // ------------------------------------------------------------------ producers
+        // ------------------------------------------------------------------ producers (in-kernel split)
         const float *am, *as, *bm, *bs;
         panel_rows(ta, pa, am, as);
         panel_rows(ta, pb, bm, bs);
@@ -302,7 +398,15 @@ __global__ __launch_bounds__(256) void gram_tile_finalize(TileFin f) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-struct TilePlan { int nt, npairs, nchunk; int64_t chunk; size_t part_bytes, gsum_bytes, ws_bytes; };
+struct TilePlan { int nt, npairs, nchunk; int64_t chunk; size_t part_bytes, gsum_bytes, planes_bytes, ws_bytes; };
+
+// pre-split planes: B >= 256 (at B = 128 a panel chunk has only 4 readers and the extra pass does not pay), K % 8 == 0
+static bool tiled_presplit(int B, int64_t K) {
+    if (getenv("KCCOT_GRAM_NO_PRESPLIT")) return false;          // =1: in-kernel split (A/B, equality test)
+    const char* f = getenv("KCCOT_GRAM_PRESPLIT");                // =1: force it from B = 128 on
+    const int minB = (f && atoi(f) == 1) ? 128 : 256;
+    return B >= minB && K % 8 == 0;
+}
 
 static TilePlan plan_tiled(int B, int64_t K) {
     TilePlan pl{};
@@ -327,7 +431,9 @@ static TilePlan plan_tiled(int B, int64_t K) {
     pl.nchunk = (int)nchunk;                                  // trailing chunks may be empty (kbeg >= K): they return at once
     pl.part_bytes = align_up((size_t)pl.npairs * pl.nchunk * TELEMS * sizeof(float), 256);
     pl.gsum_bytes = align_up((size_t)pl.npairs * TELEMS * sizeof(double), 256);
-    pl.ws_bytes = pl.part_bytes + pl.gsum_bytes;
+    // sized without looking at the environment, so that the workspace query and the launch always agree
+    pl.planes_bytes = (B >= 128 && K % 8 == 0) ? align_up((size_t)3 * 2 * B * K * sizeof(unsigned short), 256) : 0;
+    pl.ws_bytes = pl.part_bytes + pl.gsum_bytes + pl.planes_bytes;
     return pl;
 }
 
@@ -363,8 +469,18 @@ int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void*
     double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.part_bytes);
     int rc;
     if (stage != 2) {
-        TileArgs ta{cb.p[0].x, cb.p[0].y, B, pl.nt, pl.nchunk, K, pl.chunk, part};
-        hipLaunchKernelGGL(gram_tile_x3, dim3(pl.npairs * pl.nchunk), dim3(512), 0, st, ta);
+        TileArgs ta{cb.p[0].x, cb.p[0].y, B, pl.nt, pl.nchunk, K, pl.chunk, part, nullptr};
+        if (pl.planes_bytes && tiled_presplit(B, K)) {
+            unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + pl.part_bytes + pl.gsum_bytes);
+            const int64_t ngroups = (int64_t)2 * B * (K >> 3);
+            if ((ngroups + 255) / 256 > 0x7fffffff) return fail(KCCOT_EUNSUPPORTED, "pairwise_cost3(tiled): stack too large");
+            hipLaunchKernelGGL(presplit_stack, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, cb.p[0].x, cb.p[0].y, B, K, planes);
+            if ((rc = launch_status("presplit_stack"))) return rc;
+            ta.planes = planes;
+            hipLaunchKernelGGL(gram_tile_x3<true>, dim3(pl.npairs * pl.nchunk), dim3(512), 0, st, ta);
+        } else {
+            hipLaunchKernelGGL(gram_tile_x3<false>, dim3(pl.npairs * pl.nchunk), dim3(512), 0, st, ta);
+        }
         if ((rc = launch_status("gram_tile_x3"))) return rc;
         const int nvalid = (int)((K + pl.chunk - 1) / pl.chunk);
         hipLaunchKernelGGL(gram_tile_reduce, dim3(TELEMS / 256, pl.npairs), dim3(256), 0, st, (const float*)part, pl.nchunk, nvalid, gsum);

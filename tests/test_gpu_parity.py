@@ -454,6 +454,29 @@ def test_cost3_blocked_mfma_path_above_64(G, L, B, regime):
         np.testing.assert_allclose(np.diag(blocked[k]), np.diag(ref), rtol=2e-5, atol=1e-7, err_msg=tag + " diagonal")
 
 
+@pytest.mark.parametrize("B", [128, 256, 384])
+def test_tiled_gram_presplit_planes_equal_the_in_kernel_split(G, B, monkeypatch):
+    """Batches of 256 and more cut the stack [real ; fake - real] ONCE into its three exact bf16 planes
+    (presplit_stack) and the tiled Gram's producers copy from them; KCCOT_GRAM_NO_PRESPLIT=1 keeps the split inside
+    the kernel (the default at B = 128, where KCCOT_GRAM_PRESPLIT=1 forces the planes).  Same pieces, same MFMAs in
+    the same order: the three cost matrices are bit-identical."""
+    rng = np.random.default_rng(2000 + B)
+    K, T, J = 2560, 10, 8
+    real = torch.from_numpy(rng.random((B, K), dtype=np.float32)).to(DEV)
+    fake = torch.from_numpy(np.clip(real.cpu().numpy() + 0.05 * rng.standard_normal((B, K)).astype(np.float32), 0, 1)).to(DEV)
+    f = [torch.from_numpy(rng.random((B, T, J), dtype=np.float32)).to(DEV) for _ in range(4)]
+    out = {}
+    for mode in ("planes", "inkernel"):
+        monkeypatch.setenv("KCCOT_GRAM_PRESPLIT", "1")
+        if mode == "inkernel":
+            monkeypatch.setenv("KCCOT_GRAM_NO_PRESPLIT", "1")
+        out[mode] = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
+    assert _same_bits(out["planes"], out["inkernel"])
+    ref = o.modified_cost(real.cpu().numpy()[:, None, :], fake.cpu().numpy()[:, None, :], f[0].cpu().numpy(), f[2].cpu().numpy(),
+                          cases.SC, np.float64)
+    np.testing.assert_allclose(out["planes"][0], ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("B", [48, 64, 128])
 def test_cost3_gram_sums_split_equals_one_call(L, B):
     """KCCOT_COST_GRAM_SUMS_ONLY + KCCOT_COST_FROM_GRAM_SUMS (the contraction-sharded caller's two calls, here without

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Kernel-only timing of the cost-assembly stage (kccot_pairwise_cost3_f32) at a large batch.
+usage: bench_gram.py [B H T W C]; env: KCCOT_GRAM_NO_PRESPLIT, KCCOT_GRAM_PRESPLIT"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from kccotgan_amd._lib import lib, ptr, workspace, check
+B, H, T, W, C = (int(a) for a in sys.argv[1:6]) if len(sys.argv) > 5 else (256, 64, 30, 64, 3)
+K = H * T * W * C
+dev = "cuda"
+real = torch.rand(B, K, device=dev); fake = (real + 0.05 * torch.randn(B, K, device=dev)).clamp_(0, 1)
+f = [torch.rand(B, T, 8, device=dev) for _ in range(4)]
+C3 = torch.empty(3, B, B, device=dev)
+ws, wsb = workspace(lib.kccot_pairwise_cost3_workspace_bytes(B, K), real)
+def run(): check(lib.kccot_pairwise_cost3_f32(ptr(real), ptr(fake), B, K, 1 / 15.0, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), T, 8, 0, ptr(C3), ws, wsb, None), "cost3")
+for _ in range(2): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+reps = 5 if B <= 256 else 2
+e0.record()
+for _ in range(reps): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+npairs = (2 * B // 128) * (2 * B // 128 + 1) // 2
+fl = npairs * 128 * 128 * K * 2.0 * 6
+print("B=%d K=%d: cost stage %.3f ms  (%.2f PFLOP/s bf16 executed, workspace %.2f GB)  NO_PRESPLIT=%s" % (
+    B, K, ms, fl / ms / 1e12, wsb / 1e9, os.environ.get("KCCOT_GRAM_NO_PRESPLIT", "0")))
