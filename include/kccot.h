@@ -42,11 +42,11 @@ extern "C" {
 #define KCCOT_COST_FORCE_DIRECT 2u /* use the direct-difference kernel (exact (x-y)^2 form)   */
 #define KCCOT_COST_FORCE_MFMA 4u   /* use the stacked-Gram f32-MFMA kernel                    */
 #define KCCOT_COST_PARTIAL_ONLY 8u /* profiling aid: launch only the K-split partial kernel   */
+                                   /* (the dominant one); C_out is NOT written                */
 #define KCCOT_COST_GRAM_SUMS_ONLY 16u /* kccot_pairwise_cost3_f32: stop after the fp64 Gram sums (and the causal sums)  */
                                       /* are in the workspace -- nothing is written to C3                               */
 #define KCCOT_COST_FROM_GRAM_SUMS 32u /* kccot_pairwise_cost3_f32: only the finalize step, from the sums left in the    */
                                       /* SAME workspace by a GRAM_SUMS_ONLY call (real / fake are not read)             */
-                                   /* (the dominant one); C_out is NOT written                */
 
 /* Sinkhorn stop modes */
 #define KCCOT_STOP_COUNT 0         /* compute_sinkhorn: stop when err<thresh && nits >= Lmin  */

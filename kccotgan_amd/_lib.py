@@ -10,7 +10,9 @@ import os
 import torch  # must be imported first: the library then binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libkccot.so")
+# KCCOT_LIB_PATH: load another build of the SAME library (tools only: csrc/libkccot_diag.so, the diagnostic twin with
+# in-kernel stamps and timing-experiment kernel variants; never set by the package or the tests)
+LIB_PATH = os.environ.get("KCCOT_LIB_PATH") or os.path.join(_HERE, "csrc", "libkccot.so")
 
 EINVAL, EUNSUPPORTED, EWORKSPACE, EABORTED = -1, -2, -3, -4
 

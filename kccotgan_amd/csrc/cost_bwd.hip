@@ -650,12 +650,19 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
             if (rct) return rct;
             const unsigned short* Wuse = Wt3 + (row0 / 32) * (int64_t)(Rt / 16) * 512;
             (void)Wuse;
-            const char* dg = getenv("KCCOT_APPLY_DIAG");      // timing experiments only (wrong results), see the kernel
+#ifdef KCCOT_DIAG   // libkccot_diag.so only: timing experiments with WRONG results (see the kernel's header)
+            const char* dg = getenv("KCCOT_APPLY_DIAG");
             const int diag = dg ? atoi(dg) : 0;
+#else
+            const int diag = 0;
+#endif
 #define KCCOT_M256(D) hipLaunchKernelGGL(apply_coeffs_x3_m256<D>, dim3(gxb, Bout / AB_MT), dim3(512), 0, st, Wuse, Bt, Rt, s1, n1, s2, n2, K, ntiles, out)
             switch (diag) {
+#ifdef KCCOT_DIAG
                 case 1: KCCOT_M256(1); break; case 2: KCCOT_M256(2); break; case 3: KCCOT_M256(3); break;
-                case 4: KCCOT_M256(4); break; case 7: KCCOT_M256(7); break; default: KCCOT_M256(0); break;
+                case 4: KCCOT_M256(4); break; case 7: KCCOT_M256(7); break;
+#endif
+                default: KCCOT_M256(0); break;
             }
 #undef KCCOT_M256
             return launch_status("apply_coeffs_x3_m256");

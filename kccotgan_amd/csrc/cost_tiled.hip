@@ -147,7 +147,10 @@ __device__ __forceinline__ void panel_rows(const TileArgs& a, int p, const float
 // consumer wave share each SIMD, whose VALU and matrix pipe run concurrently.  One barrier per 32-k stage.
 // (The first version did both roles in every wave with one wave per SIMD: the split sat between the MFMA phases
 // and B = 512 ran slower than the blocked path.)
-template <bool PLANES>
+// DIAG (KCCOT_GRAM_TILE_DIAG, timing experiments on the PLANES build only, results are WRONG): bit 0 = the producers
+// issue no global loads; bit 1 = the consumers read their fragments once per stage instead of once per 16-k block;
+// bit 2 = no MFMAs.
+template <bool PLANES, int DIAG = 0>
 __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
     __shared__ __attribute__((aligned(16))) unsigned char zsA[TBUF];
     __shared__ __attribute__((aligned(16))) unsigned char zsB[TBUF];
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
         struct StageP { uint4 a[2][3], b[2][3]; };
         StageP s0, s1;
         auto ld = [&](const unsigned short* q, int64_t k0) {
+            if (DIAG & 1) return make_uint4((unsigned)k0, 1u, 2u, 3u);
             return (k0 + c8 + 8 <= kend) ? *reinterpret_cast<const uint4*>(q + k0) : make_uint4(0u, 0u, 0u, 0u);
         };
         auto load_stage = [&](StageP& g, int64_t k0) {
@@ -301,8 +305,10 @@ __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
         const unsigned char* zs = (s & 1) ? zsB : zsA;
 #pragma unroll
         for (int kb = 0; kb < TK / 16; ++kb) {
-            const TFrag a0 = tld_frag(zs, aoff0 + kb * 32), a1 = tld_frag(zs, aoff1 + kb * 32);
-            const TFrag b0 = tld_frag(zs, boff0 + kb * 32), b1 = tld_frag(zs, boff1 + kb * 32);
+            const int kq = (DIAG & 2) ? 0 : kb;
+            const TFrag a0 = tld_frag(zs, aoff0 + kq * 32), a1 = tld_frag(zs, aoff1 + kq * 32);
+            const TFrag b0 = tld_frag(zs, boff0 + kq * 32), b1 = tld_frag(zs, boff1 + kq * 32);
+            if (DIAG & 4) { acc00[0] += (float)a0.h[0] + (float)a1.m[0] + (float)b0.l[0] + (float)b1.h[0]; continue; }
             // product-major order: the four accumulators take turns, so no MFMA waits on the one issued before it
 #define KCCOT_T4(PA, PB)                                                                             \
             acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.PA, b0.PB, acc00, 0, 0, 0);               \
@@ -400,12 +406,14 @@ __global__ __launch_bounds__(256) void gram_tile_finalize(TileFin f) {
 // ---- host side ---------------------------------------------------------------------------------------
 struct TilePlan { int nt, npairs, nchunk; int64_t chunk; size_t part_bytes, gsum_bytes, planes_bytes, ws_bytes; };
 
-// pre-split planes: B >= 256 (at B = 128 a panel chunk has only 4 readers and the extra pass does not pay), K % 8 == 0
+// Pre-split planes are OPT-IN (KCCOT_GRAM_PRESPLIT=1): measured slower than the in-kernel split (B = 256: 1.38 vs 1.22 ms
+// for the cost stage, B = 512: 31.2 vs 26.7 ms).  The diagnostic builds showed why: with the planes the kernel itself
+// takes exactly as long as before (its producers were never the limit) and the extra pass is pure overhead -- the tile
+// kernel is bound by the bytes it pulls through L2 (B = 512: 13.6 of its 26.7 ms disappear when the producers issue no
+// loads; without MFMAs it still takes 76 % of its time), and planes are 6 bytes per element where fp32 is 4.
 static bool tiled_presplit(int B, int64_t K) {
-    if (getenv("KCCOT_GRAM_NO_PRESPLIT")) return false;          // =1: in-kernel split (A/B, equality test)
-    const char* f = getenv("KCCOT_GRAM_PRESPLIT");                // =1: force it from B = 128 on
-    const int minB = (f && atoi(f) == 1) ? 128 : 256;
-    return B >= minB && K % 8 == 0;
+    const char* f = getenv("KCCOT_GRAM_PRESPLIT");
+    return f && atoi(f) == 1 && !getenv("KCCOT_GRAM_NO_PRESPLIT") && B >= 128 && K % 8 == 0;
 }
 
 static TilePlan plan_tiled(int B, int64_t K) {
@@ -431,8 +439,7 @@ static TilePlan plan_tiled(int B, int64_t K) {
     pl.nchunk = (int)nchunk;                                  // trailing chunks may be empty (kbeg >= K): they return at once
     pl.part_bytes = align_up((size_t)pl.npairs * pl.nchunk * TELEMS * sizeof(float), 256);
     pl.gsum_bytes = align_up((size_t)pl.npairs * TELEMS * sizeof(double), 256);
-    // sized without looking at the environment, so that the workspace query and the launch always agree
-    pl.planes_bytes = (B >= 128 && K % 8 == 0) ? align_up((size_t)3 * 2 * B * K * sizeof(unsigned short), 256) : 0;
+    pl.planes_bytes = tiled_presplit(B, K) ? align_up((size_t)3 * 2 * B * K * sizeof(unsigned short), 256) : 0;
     pl.ws_bytes = pl.part_bytes + pl.gsum_bytes + pl.planes_bytes;
     return pl;
 }
@@ -477,9 +484,20 @@ int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void*
             hipLaunchKernelGGL(presplit_stack, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, cb.p[0].x, cb.p[0].y, B, K, planes);
             if ((rc = launch_status("presplit_stack"))) return rc;
             ta.planes = planes;
-            hipLaunchKernelGGL(gram_tile_x3<true>, dim3(pl.npairs * pl.nchunk), dim3(512), 0, st, ta);
+            const dim3 gg(pl.npairs * pl.nchunk);
+#ifdef KCCOT_DIAG   // libkccot_diag.so only: timing experiments with WRONG results (see the kernel's header)
+            const char* dg = getenv("KCCOT_GRAM_TILE_DIAG");
+            const int diag = dg ? atoi(dg) : 0;
+            if (diag == 1) hipLaunchKernelGGL((gram_tile_x3<true, 1>), gg, dim3(512), 0, st, ta);
+            else if (diag == 2) hipLaunchKernelGGL((gram_tile_x3<true, 2>), gg, dim3(512), 0, st, ta);
+            else if (diag == 3) hipLaunchKernelGGL((gram_tile_x3<true, 3>), gg, dim3(512), 0, st, ta);
+            else if (diag == 4) hipLaunchKernelGGL((gram_tile_x3<true, 4>), gg, dim3(512), 0, st, ta);
+            else if (diag == 5) hipLaunchKernelGGL((gram_tile_x3<true, 5>), gg, dim3(512), 0, st, ta);
+            else
+#endif
+            hipLaunchKernelGGL((gram_tile_x3<true, 0>), gg, dim3(512), 0, st, ta);
         } else {
-            hipLaunchKernelGGL(gram_tile_x3<false>, dim3(pl.npairs * pl.nchunk), dim3(512), 0, st, ta);
+            hipLaunchKernelGGL((gram_tile_x3<false, 0>), dim3(pl.npairs * pl.nchunk), dim3(512), 0, st, ta);
         }
         if ((rc = launch_status("gram_tile_x3"))) return rc;
         const int nvalid = (int)((K + pl.chunk - 1) / pl.chunk);
