@@ -46,6 +46,15 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.kccot_sinkhorn_workspace_bytes(3, 64) == 0 and lib.kccot_sinkhorn_workspace_bytes(3, 512) >= 2 * 3 * 512 * 512 * 4
     assert lib.kccot_smooth_fwd_f32(one, 2, 8, 3, 8, 1, 5.0, 3, _lib.SMOOTH_T, one, one, one, 1 << 30, None) == _lib.EINVAL  # radius >= T
     assert lib.kccot_martingale_fwd_f32(one, 0, 4, 4, 1.0, 1.0, one, None) == _lib.EINVAL
+    # round 2 entry points: fused solve + sweep, scaled cost backward, solver status
+    assert lib.kccot_sinkhorn_fused_eligible(64, 100) == 1 and lib.kccot_sinkhorn_fused_eligible(8, 100) == 1
+    assert lib.kccot_sinkhorn_fused_eligible(256, 100) == 0 and lib.kccot_sinkhorn_fused_eligible(64, 5000) == 0
+    assert lib.kccot_sinkhorn_divergence_fused_f32(one, 64, 1.0, 100, 100, 0.01, one, one, one, one, None, None) == _lib.EINVAL
+    assert lib.kccot_sinkhorn_divergence_fused_f32(one, 256, 1.0, 100, 100, 0.01, one, one, one, one, one, None) == _lib.EUNSUPPORTED
+    assert lib.kccot_sinkhorn_divergence_fused_f32(one, 64, 0.0, 100, 100, 0.01, one, one, one, one, one, None) == _lib.EINVAL
+    assert lib.kccot_pairwise_cost3_bwd_scaled_f32(one, None, one, one, 8, 64, 1.0, None, None, None, None, 1, 1, one, None, None,
+                                                   None, None, one, 1 << 20, None) == _lib.EINVAL
+    assert lib.kccot_sinkhorn_status(None, 3, None) == _lib.EINVAL
 
 
 def test_workspace_queries_are_monotone_and_cover_both_cost_paths():
