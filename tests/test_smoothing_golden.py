@@ -136,3 +136,38 @@ def test_two_phase_protocol_of_the_sharded_smoothing_hits_exactly_one(name):
         assert float(m1) == float(m2) and float(two.max()) == 1.0
         assert torch.equal(one, two)
         np.testing.assert_allclose(two.cpu().numpy(), g[key], rtol=0, atol=ATOL_3D)
+
+
+@pytest.mark.gpu
+def test_hip_smoothing_random_shapes_against_the_pinned_oracle():
+    """Ragged and odd shapes the fixtures do not hold (T barely above the radius, W*C not a multiple of 4, C = 2 / 4,
+    one-sample batches, long axes that leave the streamed kernels' range): every kernel family the dispatcher can pick
+    against the oracle that tests/test_smoothing_golden.py pins to the reference, forward and adjoint."""
+    import torch
+    from kccotgan_amd.data_utils import KernelSmoothing
+    from oracle import smoothing_np as sm
+    from oracle import smoothing_torch as st
+    rng = np.random.default_rng(77)
+    shapes = [(1, 5, 4, 6, 1), (2, 7, 5, 9, 2), (3, 9, 11, 5, 3), (1, 6, 6, 7, 4), (2, 70, 8, 6, 1), (2, 8, 66, 8, 1),
+              (1, 12, 7, 130, 1), (2, 16, 9, 16, 3), (4, 8, 8, 8, 1), (1, 33, 5, 17, 2)]
+    for shape in shapes:
+        for ksize, sigma in ((6, 5.0), (8, 1.3)):
+            r = ksize // 2
+            if min(shape[1], shape[2], shape[3]) <= r:
+                continue                                  # REFLECT needs length > radius (tf.pad raises otherwise)
+            v = rng.random(shape, dtype=np.float32)
+            ks = KernelSmoothing(ksize, ksize)
+            x = torch.from_numpy(v).cuda().requires_grad_(True)
+            for fn, ref in ((ks.temporal_convolution, sm.temporal_convolution(v, sigma, r)),
+                            (ks.gaussian_convolution3D, sm.gaussian_convolution3D_separable(v, sigma, r))):
+                out = fn(x, sigma)
+                np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=0, atol=ATOL_3D, err_msg=str((shape, ksize)))
+            # adjoint of the 3-D call against torch autograd of the oracle (max-normalisation included)
+            g = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda()
+            out = ks.gaussian_convolution3D(x, sigma)
+            (gx,) = torch.autograd.grad(out, x, g)
+            xd = torch.from_numpy(v).double().requires_grad_(True)
+            od = st.smooth(xd, sigma, r, (2, 1, 3))
+            (gd,) = torch.autograd.grad(od, xd, g.cpu().double())
+            np.testing.assert_allclose(gx.cpu().numpy(), gd.numpy(), rtol=0, atol=2e-4 * float(gd.abs().max()),
+                                       err_msg=str((shape, ksize)))
