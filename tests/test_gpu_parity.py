@@ -702,6 +702,44 @@ def test_cfg2_full_size_gradients_match_fixture(G, L, seed, regime, path):
     np.testing.assert_allclose(df.sum(1), fx["dfake_sum"], rtol=0, atol=tol * amax * np.sqrt(K) * 4)
 
 
+def test_loss_and_gradients_on_random_ragged_shapes(G):
+    """30 seeded random configurations the fixtures do not hold -- B from 1 to 70 (odd, prime, one sample, just above 64),
+    T from 2, frames down to 1 x 1, C = 1..3, J = 1..5, K not a multiple of 4 (scalar tail of the direct kernel), near and
+    far regimes, O(1) to O(100) costs -- against the fp64 torch oracle (value at 1e-4, gradients at the floor / 4 x the
+    far-regime gap).  Whatever kernel path the dispatcher picks for the shape is the one tested."""
+    rng = np.random.default_rng(20262)
+    for trial in range(30):
+        B = int(rng.choice([1, 2, 3, 5, 7, 11, 16, 23, 33, 48, 63, 65, 70]))
+        T, H, W = int(rng.integers(2, 7)), int(rng.integers(1, 7)), int(rng.integers(1, 7))
+        Cc, J = int(rng.integers(1, 4)), int(rng.integers(1, 6))
+        far = bool(rng.integers(0, 2))
+        real = rng.random((B, H, T, W, Cc), dtype=np.float32)
+        fake = rng.random(real.shape, dtype=np.float32) if far else \
+            np.clip(real + np.float32(0.05) * rng.standard_normal(real.shape, dtype=np.float32), 0, 1).astype(np.float32)
+        f = {k: rng.random((B, T, J), dtype=np.float32) for k in ("h_fake", "m_real", "h_real", "m_fake")}
+        sc = float(rng.choice([cases.SC, 1.0, 0.01]))
+        inp = dict(real=real, fake=fake, **f)
+        wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]
+        t = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+        d = {k: torch.from_numpy(v).double() for k, v in inp.items()}
+        for k in wrt:
+            t[k].requires_grad_(True)
+            d[k].requires_grad_(True)
+        loss = G.compute_sinkhorn_loss(t["real"], t["fake"], sc, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"], t["m_fake"])
+        ref = ot.compute_sinkhorn_loss(d["real"], d["fake"], sc, 0.8, 100, d["h_fake"], d["m_real"], d["h_real"], d["m_fake"])
+        tag = (trial, B, T, H, W, Cc, J, far, sc)
+        assert abs(float(loss) - float(ref)) <= 1e-4 * abs(float(ref)) + 2e-6, (tag, float(loss), float(ref))
+        grads = torch.autograd.grad(loss, [t[k] for k in wrt])
+        gref = torch.autograd.grad(ref, [d[k] for k in wrt])
+        for k, a, b in zip(wrt, grads, gref):
+            scale = float(b.abs().max())
+            if scale == 0:
+                assert float(a.abs().max()) == 0, (tag, k)
+                continue
+            tol = max(GRAD_TOL_FLOOR, GRAD_TOL_FACTOR * 2.5e-4 if far else 0.0) * 4
+            np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=tol * scale, err_msg=str((tag, k)))
+
+
 def test_general_cost_and_sinkhorn_gradients(G):
     """compute_sinkhorn (both operands differentiable, bi-causal) and the martingale penalty."""
     g, inp, t = load("small", 1, "far")
