@@ -988,6 +988,42 @@ def test_fused_solve_and_sweep_equals_the_two_kernel_path(G, shape, seed, regime
         np.testing.assert_allclose(a, b, rtol=0, atol=2 * grad_tol(name, k) * np.abs(b).max())
 
 
+@pytest.mark.parametrize("Lc", [0, 1, 3, 101, 130])
+def test_fused_path_at_degenerate_and_late_stopping_iteration_counts(G, Lc, monkeypatch):
+    """L = 0 (no iteration: plan exp(-C/eps), gan_utils.py:151 never enters the loop), 1, 3, and L > Lmin = 100 where the
+    stop rule may fire (quirk 2): fused launch == two-kernel path bit for bit, both == the fp64 oracle."""
+    g, inp, _ = load("small", 1, "far")
+    wrt = ["fake", "h_fake", "m_real"]
+
+    def run():
+        t = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+        for k in wrt:
+            t[k].requires_grad_(True)
+        loss = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.5, Lc, t["h_fake"], t["m_real"], t["h_real"], t["m_fake"],
+                                       honor_eps_l=True)
+        grads = torch.autograd.grad(loss, [t[k] for k in wrt])
+        return loss.detach().cpu().numpy().reshape(1), G.last_info["compute_sinkhorn_loss"].tolist(), [a.cpu().numpy() for a in grads]
+
+    fused = run()
+    assert bool(G.last_info["compute_sinkhorn_loss_fused_sweep"])
+    monkeypatch.setenv("KCCOT_SK_NO_FUSED", "1")
+    plain = run()
+    assert _same_bits(fused[0], plain[0]) and fused[1] == plain[1]
+    for a, b in zip(fused[2], plain[2]):
+        np.testing.assert_array_equal(a, b)
+    d = {k: torch.from_numpy(v).double() for k, v in inp.items()}
+    for k in wrt:
+        d[k].requires_grad_(True)
+    x, y = ot.flatten_video(d["real"]), ot.flatten_video(d["fake"])
+    costs = [ot.sinkhorn_from_cost(ot.modified_cost(a, b, d[h], d[m], cases.SC), 0.5, Lc) for a, b, h, m in
+             ((x, y, "h_fake", "m_real"), (x, x, "h_real", "m_real"), (y, y, "h_fake", "m_fake"))]
+    ref = 2.0 * costs[0][0] - costs[1][0] - costs[2][0]
+    assert rel(fused[0][0], ref) < 1e-4 and fused[1][:3] == [c[1] for c in costs]
+    gref = torch.autograd.grad(ref, [d[k] for k in wrt])
+    for a, b in zip(fused[2], gref):
+        np.testing.assert_allclose(a, b.numpy(), rtol=0, atol=4 * GRAD_TOL_FLOOR * float(b.abs().max()))
+
+
 # ---------------------------------------------------------------- size-independent properties at BASELINE full sizes
 FULL_SIZE = [((64, 64, 30, 64, 1), 100), ((128, 64, 30, 64, 3), 100),       # BASELINE configs[1], configs[2]
              ((256, 64, 30, 64, 3), 200), ((512, 128, 48, 128, 3), 300)]      # configs[3] (L = 200), configs[4] (L = 300)
