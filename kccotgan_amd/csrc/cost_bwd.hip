@@ -509,29 +509,30 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
     if (wave < 4) {
         // ---------------------------------------------------------------- producers (as apply_coeffs_x3)
         const int c4 = (t & 15) * 4, rp0 = t >> 4;
-        float4 v[8];
-        auto load_stage = [&](int64_t tile, int c) {
+        // TWO chunks of loads in flight per producer thread (v: even stages, w: odd stages, each set re-issued right after
+        // it has been split): a chunk is 192 MFMAs per consumer wave = 2.6 us at the matrix pipe's full rate, less than the
+        // HBM round trip under load -- with one chunk in flight the consumers waited for the producers at every barrier
+        // (the diagnostic build with NOTHING but MFMAs, barriers and these loads ran at 49 % of the 2.48 PFLOP/s that
+        // tools/micro/mfma_peak.hip sustains).
+        float4 v[8], w[8];
+        auto load_stage = [&](float4 (&dst)[8], int64_t tile, int c) {
             const int g0 = c * AM_ROWS;
             const float* base = g0 < n1 ? src1 + (int64_t)g0 * K : src2 + (int64_t)(g0 - n1) * K;
             const int64_t col = tile * AM_COLS + c4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 2 * (rp0 + 16 * (j >> 1)) + (j & 1);
-                v[j] = (col + 4 <= K) ? *reinterpret_cast<const float4*>(base + (int64_t)r * K + col)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[j] = (col + 4 <= K) ? *reinterpret_cast<const float4*>(base + (int64_t)r * K + col)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        int64_t tile = blockIdx.x;
-        int c = 0, buf = 0;
-        if (tile < ntiles) load_stage(tile, 0);
-        while (tile < ntiles) {
-            unsigned char* zb = zs + buf * AX_BUF;
+        auto split_stage = [&](const float4 (&src)[8], unsigned char* zb) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (DIAG & 4) { if (v[2 * i].x == 123456.f) zb[0] = 1; continue; }
+                if (DIAG & 4) { if (src[2 * i].x == 123456.f) zb[0] = 1; continue; }
                 const int r = 2 * (rp0 + 16 * i);
-                const float a[4] = {v[2 * i].x, v[2 * i].y, v[2 * i].z, v[2 * i].w};
-                const float b[4] = {v[2 * i + 1].x, v[2 * i + 1].y, v[2 * i + 1].z, v[2 * i + 1].w};
+                const float a[4] = {src[2 * i].x, src[2 * i].y, src[2 * i].z, src[2 * i].w};
+                const float b[4] = {src[2 * i + 1].x, src[2 * i + 1].y, src[2 * i + 1].z, src[2 * i + 1].w};
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     unsigned ha, ma, la, hb, mb, lb;
@@ -543,8 +544,27 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
                     *reinterpret_cast<unsigned*>(zb + 2 * AX_PLANE + off) = __builtin_amdgcn_perm(lb, la, 0x07060302u);
                 }
             }
-            if (++c == nchunk) { c = 0; tile += gridDim.x; }
-            if (tile < ntiles) load_stage(tile, c);
+        };
+        // stage sequence: (tile, chunk) pairs in order; `nt`/`nc` walk two stages ahead of the one being split
+        int64_t tile = blockIdx.x, nt = tile;
+        int c = 0, nc = 0, buf = 0;
+        auto advance = [&](int64_t& tt, int& cc) { if (++cc == nchunk) { cc = 0; tt += gridDim.x; } };
+        if (nt < ntiles) load_stage(v, nt, nc);
+        advance(nt, nc);
+        if (nt < ntiles) load_stage(w, nt, nc);
+        advance(nt, nc);
+        while (tile < ntiles) {
+            split_stage(v, zs + buf * AX_BUF);
+            if (nt < ntiles) load_stage(v, nt, nc);
+            advance(nt, nc);
+            advance(tile, c);
+            buf ^= 1;
+            __syncthreads();
+            if (tile >= ntiles) break;
+            split_stage(w, zs + buf * AX_BUF);
+            if (nt < ntiles) load_stage(w, nt, nc);
+            advance(nt, nc);
+            advance(tile, c);
             buf ^= 1;
             __syncthreads();
         }
@@ -622,6 +642,153 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
     }
 }
 
+// ---- 256 rows x 128 columns per workgroup: half the W bytes per MFMA ------------------------------------------------
+// tools/micro/mfma_feed.hip (profiles/r02r_micro_mfma_feed.txt): the consumer loop of apply_coeffs_x3_m256 sustains
+// 2.3-2.5 PFLOP/s chip-wide with constant operands, with its LDS fragment reads and with its barriers -- and 1.19 PFLOP/s
+// as soon as every k-step loads its six W fragments from (L2-resident) global memory: 24 KB per 96 MFMAs per CU is
+// ~19 TB/s at the matrix pipe's full rate, about twice what the L2s deliver.  Here a consumer wave owns 64 rows x 128
+// columns (2 x 4 MFMA tiles, 128 accumulator registers): the same six W fragments feed 48 MFMAs.  Stack chunks of 64 rows
+// (two 51-KB LDS buffers), staged fragments read per pair of column tiles, one pair ahead.
+constexpr int AY_ROWS = 64;                       // stack rows per staged chunk
+constexpr int AY_COLS = 128;                      // columns per workgroup tile
+constexpr int AY_COLP = AY_ROWS * 2 + 8;          // 136 bytes per column of a plane (conflict-free b64 reads)
+constexpr int AY_PLANE = AY_COLS * AY_COLP;       // 17408
+constexpr int AY_BUF = 3 * AY_PLANE;              // 52224
+
+__global__ __launch_bounds__(512) void apply_coeffs_x3_m256n128(const unsigned short* __restrict__ W3, int Bt, int Rt,
+                                                                const float* __restrict__ src1, int n1,
+                                                                const float* __restrict__ src2, int n2, int64_t K,
+                                                                int64_t ntiles, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned char zs[2 * AY_BUF];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nchunk = (n1 + n2) / AY_ROWS;                   // n1 % 64 == 0 (host)
+    const int m0 = blockIdx.y * AB_MT;
+    if (wave < 4) {
+        // ---------------------------------------------------------------- producers: 64 stack rows x 128 columns per stage
+        const int c4 = (t & 31) * 4, rp0 = t >> 5;            // column group, first row pair (0..7)
+        float4 v[8];
+        auto load_stage = [&](int64_t tile, int c) {
+            const int g0 = c * AY_ROWS;
+            const float* base = g0 < n1 ? src1 + (int64_t)g0 * K : src2 + (int64_t)(g0 - n1) * K;
+            const int64_t col = tile * AY_COLS + c4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 2 * (rp0 + 8 * (j >> 1)) + (j & 1);
+                v[j] = (col + 4 <= K) ? *reinterpret_cast<const float4*>(base + (int64_t)r * K + col)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        int64_t tile = blockIdx.x;
+        int c = 0, buf = 0;
+        if (tile < ntiles) load_stage(tile, 0);
+        while (tile < ntiles) {
+            unsigned char* zb = zs + buf * AY_BUF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * (rp0 + 8 * i);
+                const float a[4] = {v[2 * i].x, v[2 * i].y, v[2 * i].z, v[2 * i].w};
+                const float b[4] = {v[2 * i + 1].x, v[2 * i + 1].y, v[2 * i + 1].z, v[2 * i + 1].w};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    unsigned ha, ma, la, hb, mb, lb;
+                    split3u(a[cc], ha, ma, la);
+                    split3u(b[cc], hb, mb, lb);
+                    const int off = (c4 + cc) * AY_COLP + r * 2;
+                    *reinterpret_cast<unsigned*>(zb + off) = __builtin_amdgcn_perm(hb, ha, 0x07060302u);
+                    *reinterpret_cast<unsigned*>(zb + AY_PLANE + off) = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
+                    *reinterpret_cast<unsigned*>(zb + 2 * AY_PLANE + off) = __builtin_amdgcn_perm(lb, la, 0x07060302u);
+                }
+            }
+            if (++c == nchunk) { c = 0; tile += gridDim.x; }
+            if (tile < ntiles) load_stage(tile, c);
+            buf ^= 1;
+            __syncthreads();
+        }
+        __syncthreads();          // the consumers' closing barrier
+        return;
+    }
+    // -------------------------------------------------------------------- consumers
+    const int w = wave - 4;                                   // rows m0 + 64 w .. + 63, all 128 columns
+    const int nsteps = Rt >> 4;                               // k-steps per tile (a multiple of 4)
+    const int64_t plane = (int64_t)Bt * Rt;
+    const unsigned short* wb0 = W3 + (int64_t)((m0 + 64 * w) / 32) * nsteps * 512 + lane * 8;
+    const unsigned short* wb1 = wb0 + (int64_t)nsteps * 512;
+    abf16x8 A[2][2][3];                                       // k-step g lives in A[g & 1]: one step (48 MFMAs) ahead
+    auto ldA = [&](int g, int slot) {
+        const int64_t o = (int64_t)512 * g;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            A[slot][0][pl] = *reinterpret_cast<const abf16x8*>(wb0 + pl * plane + o);
+            A[slot][1][pl] = *reinterpret_cast<const abf16x8*>(wb1 + pl * plane + o);
+        }
+    };
+    ldA(0, 0);
+    const int boff = (lane & 31) * AY_COLP + 16 * (lane >> 5);
+    int buf = 0;
+    __syncthreads();                                          // the first stage is in buffer 0
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int c = 0; c < nchunk; ++c, buf ^= 1) {
+            const unsigned char* zb = zs + buf * AY_BUF;
+            abf16x8 Bf[2][2][3];                              // [pair parity][column tile of the pair][piece]
+            auto ldB = [&](int st, int pair, int par) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        uint2* q = reinterpret_cast<uint2*>(&Bf[par][j][pl]);
+                        const unsigned char* src = zb + pl * AY_PLANE + boff + (64 * pair + 32 * j) * AY_COLP + 32 * st;
+                        q[0] = *reinterpret_cast<const uint2*>(src);
+                        q[1] = *reinterpret_cast<const uint2*>(src + 8);
+                    }
+            };
+            ldB(0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                int gn = c * 4 + s + 1;
+                if (gn >= nsteps) gn -= nsteps;
+                ldA(gn, (s + 1) & 1);
+#pragma unroll
+                for (int pair = 0; pair < 2; ++pair) {
+                    // the NEXT pair's staged fragments (or the next step's first pair) while this pair's MFMAs run
+                    if (pair == 0) ldB(s, 1, 1);
+                    else if (s < 3) ldB(s + 1, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#define KCCOT_A4(PA, PB)                                                                                                         \
+                    acc[0][2 * pair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0][PA], Bf[pair][0][PB], acc[0][2 * pair], 0, 0, 0);         \
+                    acc[0][2 * pair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0][PA], Bf[pair][1][PB], acc[0][2 * pair + 1], 0, 0, 0); \
+                    acc[1][2 * pair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][1][PA], Bf[pair][0][PB], acc[1][2 * pair], 0, 0, 0);         \
+                    acc[1][2 * pair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][1][PA], Bf[pair][1][PB], acc[1][2 * pair + 1], 0, 0, 0);
+                    KCCOT_A4(1, 1) KCCOT_A4(0, 2) KCCOT_A4(2, 0) KCCOT_A4(0, 1) KCCOT_A4(1, 0) KCCOT_A4(0, 0)
+#undef KCCOT_A4
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();                                  // this stage is consumed; the next one is staged
+        }
+        const int64_t col0 = tile * AY_COLS + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t col = col0 + 32 * j;
+            if (col < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = m0 + 64 * w + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    out[m * K + col] = acc[0][j][r];
+                    out[(m + 32) * K + col] = acc[1][j][r];
+                }
+            }
+        }
+    }
+}
+
 // Wt points at the first wanted output row's column; wpitch = full number of output rows of W
 // W3 (optional): the three bf16 planes of the SAME coefficients, [3][Bt][Rt] (split_coeffs), positioned at the first
 // wanted output row; selects the exact bf16 kernel when the stack is a multiple of 16 rows.
@@ -649,7 +816,18 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
             int rct = launch_status("retile_coeffs");
             if (rct) return rct;
             const unsigned short* Wuse = Wt3 + (row0 / 32) * (int64_t)(Rt / 16) * 512;
-            (void)Wuse;
+            // 128-column tiles (half the W bytes per MFMA) once there are >= 20 of them per workgroup -- below that the
+            // tail of the persistent tile loop costs more than the W stream saves (B = 256, K = 368 640: 0.73 vs 0.68 ms;
+            // B = 512, K = 2.36 M: 13.2 vs 13.8 ms).  KCCOT_APPLY_M256_N64=1 / =0 force the 64- / 128-column form.
+            const char* n64 = getenv("KCCOT_APPLY_M256_N64");
+            const int64_t nt128 = (K + AY_COLS - 1) / AY_COLS;
+            const bool wide = n64 ? atoi(n64) == 0 : nt128 >= 20 * 256;
+            if (wide && n1 % AY_ROWS == 0 && n2 % AY_ROWS == 0) {
+                const unsigned gy = (unsigned)(nt128 < 256 ? nt128 : 256);
+                hipLaunchKernelGGL(apply_coeffs_x3_m256n128, dim3(gy, Bout / AB_MT), dim3(512), 0, st, Wuse, Bt, Rt, s1, n1, s2, n2,
+                                   K, nt128, out);
+                return launch_status("apply_coeffs_x3_m256n128");
+            }
 #ifdef KCCOT_DIAG   // libkccot_diag.so only: timing experiments with WRONG results (see the kernel's header)
             const char* dg = getenv("KCCOT_APPLY_DIAG");
             const int diag = dg ? atoi(dg) : 0;

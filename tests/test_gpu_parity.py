@@ -1119,6 +1119,29 @@ def test_full_size_configs_3_and_4_against_the_oracle(G, shape, Lc):
         assert abs(float(rbf_mmd2(real, real.clone()))) <= 1e-6
 
 
+@pytest.mark.parametrize("form", ["0", "1"])
+def test_large_batch_video_gradient_forms_agree(G, form, monkeypatch):
+    """B = 256: the one-launch 256-row-tile video gradient in its 64-column (KCCOT_APPLY_M256_N64=1) and 128-column
+    (=0) forms against the 64-row block form (KCCOT_APPLY_NO_M256=1): same exact split, same products, another tiling
+    of the stack -- equal to fp32 summation order (1e-6 of max|grad|)."""
+    B, H, T, W, C = 256, 8, 10, 8, 5          # K = 3200: 25 column tiles of 128, the last one partial for 64 / full for 128
+    gen = torch.Generator(device=DEV).manual_seed(4242)
+    real = torch.rand((B, H, T, W, C), device=DEV, generator=gen)
+    fake = (real + 0.05 * torch.randn(real.shape, device=DEV, generator=gen)).clamp_(0, 1)
+    f = {k: torch.rand((B, T, 8), device=DEV, generator=gen) for k in ("h_fake", "m_real", "h_real", "m_fake")}
+    grads = {}
+    for mode in ("tile", "block"):
+        if mode == "tile":
+            monkeypatch.setenv("KCCOT_APPLY_M256_N64", form)
+        else:
+            monkeypatch.setenv("KCCOT_APPLY_NO_M256", "1")
+        fk = fake.clone().requires_grad_(True)
+        loss = G.compute_sinkhorn_loss(real, fk, cases.SC, 0.8, 100, f["h_fake"], f["m_real"], f["h_real"], f["m_fake"])
+        (grads[mode],) = torch.autograd.grad(loss, fk)
+    scale = float(grads["block"].abs().max())
+    assert float((grads["tile"] - grads["block"]).abs().max()) <= 1e-6 * scale
+
+
 def test_video_gradient_bf16_split_matches_f32_mfma(G):
     """dfake = W [X;Y] on the bf16 matrix pipe (exact three-way split of W and of the videos, the default) against
     the f32-input MFMA kernel (KCCOT_APPLY_F32=1) at configs[1] full size and at a blocked batch (B = 128)."""
