@@ -494,6 +494,10 @@ def main():
                                  "f32_mfma_equivalent": alg_flops / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e6},
                     "executed_bf16_mfma_tflops": exec_flops / t_s / 1e12,
                     "bf16_mfma_frac": exec_flops / t_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "bf16_mfma_frac_of_measured_sustained": exec_flops / t_s / 1e12 / 1750.0,
+                    "measured_sustained_note": "v_mfma_f32_32x32x16_bf16 sustains 2.48 PFLOP/s with constant operands and 1.72-1.82 "
+                                               "with data-like operand bits on this part (tools/micro/mfma_feed.hip, "
+                                               "profiles/r02r_micro_mfma_feed.txt); informational, `peak` stays the guide's figure",
                     "f32_mfma_equivalent": {"achieved_tflops": tfl, "peak": MFMA_F32_PEAK_TFLOPS,
                                             "frac": tfl / MFMA_F32_PEAK_TFLOPS,
                                             "note": "algorithmic fp32 flops / time against the f32-input MFMA peak; "
