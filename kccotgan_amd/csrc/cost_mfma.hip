@@ -465,6 +465,95 @@ __device__ __forceinline__ void x3ws_consume(const unsigned char* zsA, const uns
 // that share a SIMD run concurrently: the staging no longer sits between the MFMA phases of the
 // same wave.  One s_barrier per stage (every wave executes the same number of them).
 // ------------------------------------------------------------------------------------------
+// Producer side with TWO stages of loads in flight (register sets v: even stages, w: odd stages).  Everything the
+// steady-state loop does is unconditional: rows and k offsets are CLAMPED into the tensor and the out-of-range values are
+// replaced by zeros with selects after the wait, so that the compiler sees straight-line load / use code and waits with
+// partial counters (vmcnt(8..15): only the OLDER set has to have landed).  With predicated loads (ld4) it falls back to
+// s_waitcnt vmcnt(0) directly behind the issue and the second set buys nothing (measured: round 2).
+// The loop is peeled so that the number of outstanding loads at every wait is static: prologue 2 sets, steady state
+// (s + 3 < nstage) re-issues both, the last 2 or 3 stages drain.  Barrier count = nstage + 1, as the consumers'.
+struct DeepSet { float4 x[8]; };
+
+__device__ __forceinline__ void x3ws_issue(DeepSet& d, const float* const (&rp)[8], int64_t koff) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d.x[j] = *reinterpret_cast<const float4*>(rp[j] + koff);
+}
+
+template <bool MASK>
+__device__ __forceinline__ void x3ws_emit(DeepSet& d, const bool (&ok)[8], bool kok, bool pair_diff, unsigned char* zb,
+                                          int wbase) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float4 a = d.x[j], b = d.x[j + 4];
+        if (MASK) {
+            const bool va = ok[j] && kok, vb = ok[j + 4] && kok;
+            a.x = va ? a.x : 0.f; a.y = va ? a.y : 0.f; a.z = va ? a.z : 0.f; a.w = va ? a.w : 0.f;
+            b.x = vb ? b.x : 0.f; b.y = vb ? b.y : 0.f; b.z = vb ? b.z : 0.f; b.w = vb ? b.w : 0.f;
+        }
+        if (pair_diff) { b.x -= a.x; b.y -= a.y; b.z -= a.z; b.w -= a.w; }
+        // (the subtractions as packed v_pk_add_f32, half as many instructions, measured SLOWER: 20.7-21.2 us vs 19.1-20.4)
+        split3_store(zb, wbase + 16 * j * XPITCH, a);
+        split3_store(zb, wbase + (64 + 16 * j) * XPITCH, b);
+    }
+}
+
+template <bool MASK>
+__device__ __forceinline__ void x3ws_produce_deep_impl(const GramArgs& ga, unsigned char* zsA, unsigned char* zsB, int t,
+                                                  int64_t kbeg, int64_t kend, int nstage) {
+    const int r0 = t >> 4, c4 = (t & 15) * 4;
+    const float* rp[8];
+    bool ok[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = r0 + 16 * (j & 3);
+        ok[j] = r < (j < 4 ? ga.n1 : ga.n2);
+        rp[j] = (j < 4 ? ga.src1 : ga.src2) + (int64_t)(ok[j] ? r : 0) * ga.K;
+    }
+    const int wbase = r0 * XPITCH + c4 * 2;
+    const int64_t kmax = ga.K - 4;                                        // K >= 4 (host check)
+    auto koff = [&](int s) { const int64_t k = kbeg + (int64_t)s * XKT + c4; return k < kmax ? k : kmax; };
+    auto kok = [&](int s) { return kbeg + (int64_t)s * XKT + c4 + 4 <= kend; };
+    const bool pd = ga.pair_diff;
+    DeepSet v, w;
+    x3ws_issue(v, rp, koff(0));
+    x3ws_issue(w, rp, koff(1));                                           // nstage >= 2 (caller)
+    int s = 0;
+    for (; s + 3 < nstage; s += 2) {
+        x3ws_emit<MASK>(v, ok, kok(s), pd, zsA, wbase);
+        x3ws_issue(v, rp, koff(s + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        x3ws_emit<MASK>(w, ok, kok(s + 1), pd, zsB, wbase);
+        x3ws_issue(w, rp, koff(s + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    // s + 1 < nstage <= s + 3: two or three stages left, v = stage s, w = stage s + 1
+    const bool three = s + 2 < nstage;
+    x3ws_emit<MASK>(v, ok, kok(s), pd, zsA, wbase);
+    if (three) x3ws_issue(v, rp, koff(s + 2));
+    __syncthreads();
+    x3ws_emit<MASK>(w, ok, kok(s + 1), pd, zsB, wbase);
+    __syncthreads();
+    if (three) {
+        x3ws_emit<MASK>(v, ok, kok(s + 2), pd, zsA, wbase);
+        __syncthreads();
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void x3ws_produce_deep(const GramArgs& ga, unsigned char* zsA, unsigned char* zsB, int t,
+                                                  int64_t kbeg, int64_t kend, int nstage) {
+    // uniform: full row blocks and whole stages need no masking at all
+    const bool whole = ga.n1 == 64 && ga.n2 == 64 && kend - kbeg == (int64_t)nstage * XKT;
+#if defined(KCCOT_GRAM_EXP) && KCCOT_GRAM_EXP == 2
+    for (int s = 0; s <= nstage; ++s) __syncthreads();   // diagnostic build: producers only keep the barriers
+    return;
+#endif
+    if (whole) x3ws_produce_deep_impl<false>(ga, zsA, zsB, t, kbeg, kend, nstage);
+    else x3ws_produce_deep_impl<true>(ga, zsA, zsB, t, kbeg, kend, nstage);
+}
+
 template <bool gram_two_deep>
 __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
     __shared__ __attribute__((aligned(16))) unsigned char zsA[3 * XPLANE];
@@ -489,6 +578,10 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
 
     if (wave < 4) {
         // ------------------------------------------------------------------ producers
+        if (gram_two_deep && nstage >= 2) {
+            x3ws_produce_deep(ga, zsA, zsB, t, kbeg, kend, nstage);
+            return;
+        }
         const int r0 = t >> 4, c4 = (t & 15) * 4;
         const float* rp[8];
         bool ok[8];
@@ -499,18 +592,10 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
             rp[j] = (j < 4 ? ga.src1 : ga.src2) + (int64_t)r * ga.K;
         }
         const int wbase = r0 * XPITCH + c4 * 2;
-        // gram_two_deep (KCCOT_GRAM_DEEP=1, off by default): two stages of loads in flight per producer
-        // thread (v: even stages, w: odd stages; each set is re-issued right after it has been consumed):
-        // 64 KB outstanding per CU instead of 32 KB.  Measured 22.1-22.6 us against 20.4-21.3 us for one
-        // stage in flight (tools/ab_gram.sh): the stream is not limited by bytes in flight.
-        float4 v[8], w[8];
-        const bool deep = gram_two_deep;
+        // one stage of loads in flight (predicated loads; chunks of a single stage, and the A/B reference for the deep form)
+        float4 v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kbeg + c4, kend, ok[j]);
-        if (deep && nstage > 1) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = ld4(rp[j], kbeg + XKT + c4, kend, ok[j]);
-        }
         for (int s = 0; s <= nstage; ++s) {
             // stage s goes into buffer s&1 (the consumers read it during iteration s+1 of this loop)
 #if defined(KCCOT_GRAM_EXP) && KCCOT_GRAM_EXP == 2
@@ -519,40 +604,23 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
             if (s < nstage) {
 #endif
                 unsigned char* zb = (s & 1) ? zsB : zsA;
-                if (!deep || (s & 1) == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; ++j) {
 #if defined(KCCOT_GRAM_EXP) && KCCOT_GRAM_EXP == 3
-                        // diagnostic build: global loads only, one cheap use so that they are not dropped
-                        if (v[j].x + v[j + 4].x == 1234.5f) zb[wbase] = 1;
-                        continue;
+                    // diagnostic build: global loads only, one cheap use so that they are not dropped
+                    if (v[j].x + v[j + 4].x == 1234.5f) zb[wbase] = 1;
+                    continue;
 #endif
-                        if (ga.pair_diff) {
-                            v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
-                        }
-                        split3_store(zb, wbase + 16 * j * XPITCH, v[j]);
-                        split3_store(zb, wbase + (64 + 16 * j) * XPITCH, v[j + 4]);
+                    if (ga.pair_diff) {
+                        v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
                     }
-                    const int ahead = deep ? 2 : 1;
-                    if (s + ahead < nstage) {
-                        const int64_t kn = kbeg + (int64_t)(s + ahead) * XKT;
+                    split3_store(zb, wbase + 16 * j * XPITCH, v[j]);
+                    split3_store(zb, wbase + (64 + 16 * j) * XPITCH, v[j + 4]);
+                }
+                if (s + 1 < nstage) {
+                    const int64_t kn = kbeg + (int64_t)(s + 1) * XKT;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kn + c4, kend, ok[j]);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (ga.pair_diff) {
-                            w[j + 4].x -= w[j].x; w[j + 4].y -= w[j].y; w[j + 4].z -= w[j].z; w[j + 4].w -= w[j].w;
-                        }
-                        split3_store(zb, wbase + 16 * j * XPITCH, w[j]);
-                        split3_store(zb, wbase + (64 + 16 * j) * XPITCH, w[j + 4]);
-                    }
-                    if (s + 2 < nstage) {
-                        const int64_t kn = kbeg + (int64_t)(s + 2) * XKT;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) w[j] = ld4(rp[j], kn + c4, kend, ok[j]);
-                    }
+                    for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kn + c4, kend, ok[j]);
                 }
             }
             __syncthreads();
@@ -835,8 +903,10 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
             // 16 spare workgroups (one per CU the 240-way K-split leaves idle) take the causal tiles
             int spare = 0;
             if (ncausal > 0 && !partial_only) { spare = ncausal < 16 ? ncausal : 16; ga.ntiles = ncausal; ncausal = 0; }
-            const char* d = getenv("KCCOT_GRAM_DEEP");   // =1: two stages of loads in flight (A/B: measured 1-2 us SLOWER)
-            if (d && atoi(d) == 1) hipLaunchKernelGGL(gram128_partial_x3ws<true>, dim3(pl.nchunk + spare), dim3(512), 0, st, ga);
+            // two stages of loads in flight (unconditional clamped loads, x3ws_produce_deep): 19.1-20.4 us against
+            // 21.0-21.8 us for one stage with predicated loads (KCCOT_GRAM_DEEP=0, kept as the A/B reference)
+            const char* d = getenv("KCCOT_GRAM_DEEP");
+            if (!d || atoi(d) != 0) hipLaunchKernelGGL(gram128_partial_x3ws<true>, dim3(pl.nchunk + spare), dim3(512), 0, st, ga);
             else hipLaunchKernelGGL(gram128_partial_x3ws<false>, dim3(pl.nchunk + spare), dim3(512), 0, st, ga);
             split_mode = GRAM_SPLIT_26;
         }

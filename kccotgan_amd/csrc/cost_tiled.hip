@@ -142,6 +142,98 @@ __device__ __forceinline__ void panel_rows(const TileArgs& a, int p, const float
     else { main = a.fake + (int64_t)(r0 - a.B) * a.K; sub = a.real + (int64_t)(r0 - a.B) * a.K; }
 }
 
+// Producer side of gram_tile_x3 (in-kernel split).  Thread: the float4 at columns c4..c4+3 of panel rows r0 + 32 j, j < 4,
+// of both panels.  TWO stages of loads are in flight per producer thread (set 0: even stages, set 1: odd stages; a set
+// is re-issued right after it has been split): with GBs of video behind the stream the HBM latency under load is several
+// stage times.  For that to work the compiler must see STRAIGHT-LINE loads in the steady state -- with loads predicated on
+// "subtrahend present", "off-diagonal pair" or "k inside the chunk" it waits with s_waitcnt vmcnt(0) right behind the
+// issue and the second set buys nothing (round 2 finding).  So: AS / BS / SAME are template
+// parameters, k offsets are clamped into the row and a ragged last stage is zeroed by selects after the wait, and the
+// loop is peeled (prologue: two sets; steady state s + 3 < nstage: both re-issued; last two or three stages drain) so
+// that the number of loads outstanding at every wait is static.  Barriers: nstage + 1, like the consumers.
+struct TStageRegs { float4 va[4], vb[4], qa[4], qb[4]; };
+
+template <bool AS, bool BS, bool SAME>
+__device__ __forceinline__ void tile_issue(TStageRegs& g, const float* am, const float* as, const float* bm,
+                                           const float* bs, int64_t rstep, int64_t koff) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t o = j * rstep + koff;
+        g.va[j] = *reinterpret_cast<const float4*>(am + o);
+        if (AS) g.qa[j] = *reinterpret_cast<const float4*>(as + o);
+        if (!SAME) {
+            g.vb[j] = *reinterpret_cast<const float4*>(bm + o);
+            if (BS) g.qb[j] = *reinterpret_cast<const float4*>(bs + o);
+        }
+    }
+}
+
+template <bool AS, bool BS, bool SAME>
+__device__ __forceinline__ void tile_emit(TStageRegs& g, bool kok, unsigned char* zb, int wbase) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float4 a = g.va[j];
+        if (AS) { a.x -= g.qa[j].x; a.y -= g.qa[j].y; a.z -= g.qa[j].z; a.w -= g.qa[j].w; }
+        a.x = kok ? a.x : 0.f; a.y = kok ? a.y : 0.f; a.z = kok ? a.z : 0.f; a.w = kok ? a.w : 0.f;
+        tsplit3_store(zb, wbase + 32 * j * TPITCH, a);
+        if (!SAME) {
+            float4 b = g.vb[j];
+            if (BS) { b.x -= g.qb[j].x; b.y -= g.qb[j].y; b.z -= g.qb[j].z; b.w -= g.qb[j].w; }
+            b.x = kok ? b.x : 0.f; b.y = kok ? b.y : 0.f; b.z = kok ? b.z : 0.f; b.w = kok ? b.w : 0.f;
+            tsplit3_store(zb, wbase + (TP + 32 * j) * TPITCH, b);
+        }
+    }
+}
+
+template <bool AS, bool BS, bool SAME>
+__device__ __forceinline__ void tile_produce(const float* am, const float* as, const float* bm, const float* bs, int64_t K,
+                                             int64_t kbeg, int64_t kend, int nstage, int t, unsigned char* zsA,
+                                             unsigned char* zsB) {
+    const int r0 = t >> 3, c4 = (t & 7) * 4;
+    const int64_t roff = (int64_t)r0 * K, rstep = 32 * K;
+    const int wbase = r0 * TPITCH + c4 * 2;
+    am += roff; bm += roff;
+    if (AS) as += roff;
+    if (BS) bs += roff;
+    const int64_t kmax = K - 4;                                            // K % 4 == 0, K >= TK (host checks)
+    auto koff = [&](int s) { const int64_t k = kbeg + (int64_t)s * TK + c4; return k < kmax ? k : kmax; };
+    auto kok = [&](int s) { return kbeg + (int64_t)s * TK + c4 + 4 <= kend; };   // false only in a ragged last stage
+    TStageRegs s0, s1;
+    if (nstage < 2) {
+        tile_issue<AS, BS, SAME>(s0, am, as, bm, bs, rstep, koff(0));
+        tile_emit<AS, BS, SAME>(s0, kok(0), zsA, wbase);
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
+    tile_issue<AS, BS, SAME>(s0, am, as, bm, bs, rstep, koff(0));
+    tile_issue<AS, BS, SAME>(s1, am, as, bm, bs, rstep, koff(1));
+    int s = 0;
+    for (; s + 3 < nstage; s += 2) {
+        // stage s goes into buffer A, stage s + 1 into buffer B (the consumers read a buffer one barrier later)
+        tile_emit<AS, BS, SAME>(s0, true, zsA, wbase);
+        tile_issue<AS, BS, SAME>(s0, am, as, bm, bs, rstep, koff(s + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        tile_emit<AS, BS, SAME>(s1, true, zsB, wbase);
+        tile_issue<AS, BS, SAME>(s1, am, as, bm, bs, rstep, koff(s + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    // s + 1 < nstage <= s + 3: two or three stages left (only the very last one can be ragged)
+    const bool three = s + 2 < nstage;
+    tile_emit<AS, BS, SAME>(s0, kok(s), zsA, wbase);
+    if (three) tile_issue<AS, BS, SAME>(s0, am, as, bm, bs, rstep, koff(s + 2));
+    __syncthreads();
+    tile_emit<AS, BS, SAME>(s1, kok(s + 1), zsB, wbase);
+    __syncthreads();
+    if (three) {
+        tile_emit<AS, BS, SAME>(s0, kok(s + 2), zsA, wbase);
+        __syncthreads();
+    }
+    __syncthreads();
+}
+
 // Wave-specialised like gram128_partial_x3ws: waves 0-3 PRODUCE (global loads, E = fake - real, three-way split,
 // ds_write into the next LDS buffer), waves 4-7 CONSUME (ds_read + MFMA on the current buffer): a producer and a
 // consumer wave share each SIMD, whose VALU and matrix pipe run concurrently.  One barrier per 32-k stage.
@@ -227,55 +319,17 @@ __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
         const float *am, *as, *bm, *bs;
         panel_rows(ta, pa, am, as);
         panel_rows(ta, pb, bm, bs);
-        // thread holds the float4 at columns c4..c4+3 of panel rows r0 + 32 j, j < 4, of both panels
-        const int r0 = t >> 3, c4 = (t & 7) * 4;
-        const int64_t roff = (int64_t)r0 * K, rstep = 32 * K;
-        const int wbase = r0 * TPITCH + c4 * 2;
-        // TWO stages of loads are in flight per producer thread (set 0: even stages, set 1: odd stages; a set is
-        // re-issued right after it has been split): with GBs of video behind the stream the HBM latency under load is
-        // several stage times, and one stage of prefetch left the producers waiting on every barrier interval.
-        // E = fake - real is formed when a stage is split, so a producer never waits on a load it has just issued.
-        struct StageRegs { float4 va[4], vb[4], qa[4], qb[4]; };
-        StageRegs s0, s1;
-        auto load_stage = [&](StageRegs& g, int64_t k0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t o = roff + j * rstep;
-                g.va[j] = tld4(am + o, k0 + c4, kend);
-                if (as) g.qa[j] = tld4(as + o, k0 + c4, kend);
-                if (!same) {
-                    g.vb[j] = tld4(bm + o, k0 + c4, kend);
-                    if (bs) g.qb[j] = tld4(bs + o, k0 + c4, kend);
-                }
-            }
-        };
-        auto split_stage = [&](StageRegs& g, unsigned char* zb) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (as) { g.va[j].x -= g.qa[j].x; g.va[j].y -= g.qa[j].y; g.va[j].z -= g.qa[j].z; g.va[j].w -= g.qa[j].w; }
-                tsplit3_store(zb, wbase + 32 * j * TPITCH, g.va[j]);
-                if (!same) {
-                    if (bs) { g.vb[j].x -= g.qb[j].x; g.vb[j].y -= g.qb[j].y; g.vb[j].z -= g.qb[j].z; g.vb[j].w -= g.qb[j].w; }
-                    tsplit3_store(zb, wbase + (TP + 32 * j) * TPITCH, g.vb[j]);
-                }
-            }
-        };
-        load_stage(s0, kbeg);
-        if (nstage > 1) load_stage(s1, kbeg + TK);
-        for (int s = 0; s <= nstage; s += 2) {
-            // stage s goes into buffer A, stage s + 1 into buffer B (the consumers read a buffer one barrier later)
-            if (s < nstage) {
-                split_stage(s0, zsA);
-                if (s + 2 < nstage) load_stage(s0, kbeg + (int64_t)(s + 2) * TK);
-            }
-            __syncthreads();
-            if (s + 1 <= nstage) {
-                if (s + 1 < nstage) {
-                    split_stage(s1, zsB);
-                    if (s + 3 < nstage) load_stage(s1, kbeg + (int64_t)(s + 3) * TK);
-                }
-                __syncthreads();
-            }
+        // which tensors a stage reads is fixed per workgroup: one instantiation per combination, so that the loads in the
+        // stage loop are unconditional (see tile_produce)
+        if (same) {
+            if (as) tile_produce<true, true, true>(am, as, bm, bs, K, kbeg, kend, nstage, t, zsA, zsB);
+            else tile_produce<false, false, true>(am, as, bm, bs, K, kbeg, kend, nstage, t, zsA, zsB);
+        } else if (as) {
+            tile_produce<true, true, false>(am, as, bm, bs, K, kbeg, kend, nstage, t, zsA, zsB);      // pa <= pb: bs too
+        } else if (bs) {
+            tile_produce<false, true, false>(am, as, bm, bs, K, kbeg, kend, nstage, t, zsA, zsB);
+        } else {
+            tile_produce<false, false, false>(am, as, bm, bs, K, kbeg, kend, nstage, t, zsA, zsB);
         }
         return;
     }

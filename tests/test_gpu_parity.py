@@ -477,6 +477,28 @@ def test_tiled_gram_presplit_planes_equal_the_in_kernel_split(G, B, monkeypatch)
     np.testing.assert_allclose(out["planes"][0], ref, rtol=0, atol=1e-5 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("B,K", [(64, 122880), (64, 4100), (37, 3076), (7, 256), (64, 64 * 300 + 36), (33, 128)])
+def test_gram_two_stage_producers_equal_the_one_stage_form(G, B, K, monkeypatch):
+    """The default producers of gram128_partial_x3ws keep two stages of UNCONDITIONAL (clamped) loads in flight and zero
+    the out-of-range values with selects; KCCOT_GRAM_DEEP=0 is the one-stage form with predicated loads.  Same values into
+    the same MFMAs in the same order: bit-identical cost matrices, including ragged row blocks (B < 64), K-chunks that
+    end inside a stage, chunks of one or two stages and K that is no multiple of the stage."""
+    rng = np.random.default_rng(77 + B + K)
+    T, J = 6, 4
+    real = torch.from_numpy(rng.random((B, K), dtype=np.float32)).to(DEV)
+    fake = (real + 0.02 * torch.randn(B, K, device=DEV)).clamp_(0, 1).contiguous()
+    f = [torch.from_numpy(rng.random((B, T, J), dtype=np.float32)).to(DEV) for _ in range(4)]
+    out = {}
+    for mode in ("deep", "shallow"):
+        if mode == "shallow":
+            monkeypatch.setenv("KCCOT_GRAM_DEEP", "0")
+        else:
+            monkeypatch.delenv("KCCOT_GRAM_DEEP", raising=False)
+        out[mode] = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
+    assert np.isfinite(out["deep"]).all()
+    assert _same_bits(out["deep"], out["shallow"])
+
+
 @pytest.mark.parametrize("B", [48, 64, 128])
 def test_cost3_gram_sums_split_equals_one_call(L, B):
     """KCCOT_COST_GRAM_SUMS_ONLY + KCCOT_COST_FROM_GRAM_SUMS (the contraction-sharded caller's two calls, here without

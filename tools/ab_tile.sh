@@ -1,0 +1,11 @@
+set -o pipefail
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "tiled or gram or full_size or large_batch or cost" > gpurun_out/r02y_tests.log 2>&1; tail -3 gpurun_out/r02y_tests.log
+for rep in 1 2; do
+for lib in old new; do
+  p=$PWD/kccotgan_amd/csrc/libkccot.so; [ $lib = old ] && p=$PWD/kccotgan_amd/csrc/libkccot_old.so
+  echo "== $lib"
+  KCCOT_LIB_PATH=$p python tools/bench_gram.py 128 64 30 64 1 &&
+  KCCOT_LIB_PATH=$p python tools/bench_gram.py 256 64 30 64 3 &&
+  KCCOT_LIB_PATH=$p python tools/bench_gram.py 512 128 48 128 3 || exit 1
+done
+done
