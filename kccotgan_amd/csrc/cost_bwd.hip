@@ -364,6 +364,9 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3(const unsigned short* __r
             rowok[j] = r < rr;
             rowp[j] = r < n1 ? src1 + (int64_t)r * K : src2 + (int64_t)(r - n1) * K;
         }
+        // (one tile of loads in flight.  The Gram kernels' remedy -- two sets of unconditional clamped loads, peeled loop --
+        // was measured here too: bit-identical, 23.07 us against 22.50 us at configs[1]; this kernel already moves its
+        // 94 MB of reads + writes at 4.2 TB/s.  profiles/r02z_prof_ab.txt)
         float4 v[8];
         auto load_tile = [&](int64_t tile) {
             const int64_t col = tile * AM_COLS + c4;
