@@ -346,7 +346,31 @@ __global__ __launch_bounds__(NT) void smooth_plane(PlaneArgs a) {
 // Adjoint weights: w_k(p) = w[k] + [p >= 1] w[-2p-k] + [p <= L-2] w[2(L-1)-2p-k] (taps outside -R..R
 // are zero), sources outside [0,L) do not exist; the head fold is known at compile time, the tail
 // fold depends on d = L-1-p and is chosen with scalar selects.
-enum { WALK_MAX = 0, WALK_WRITE = 1, WALK_RAW = 2, WALK_ADJ = 3, WALK_ADJX = 4 };
+enum { WALK_MAX = 0, WALK_WRITE = 1, WALK_RAW = 2, WALK_ADJ = 3, WALK_ADJX = 4, WALK_COOP = 5, WALK_RAW_TW = 6 };
+
+// WALK_RAW_TW (C == 1, four consecutive w per thread, W/4 a power of two <= 64): the T walk with the W stencil of
+// smooth_w1 applied to every T-smoothed piece before it is stored -- the left / right neighbour pieces of a row are the
+// neighbouring LANES' registers (one row = W/4 consecutive lanes of a wave), fetched with DPP wave shifts; REFLECT at the
+// row ends as in smooth_w1.  Same fma order as the two kernels it replaces (bit-identical), one read + one write of the
+// tensor less.
+__device__ __forceinline__ float from_prev_lane(float v) {   // lane i <- lane i - 1
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_next_lane(float v) {   // lane i <- lane i + 1
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+// WALK_COOP: WALK_MAX and WALK_WRITE in ONE launch, for tensors that fit the register files of the device (one line of
+// the axis per thread, all workgroups resident): every thread keeps its smoothed line in registers, the workgroups
+// publish their maxima and meet at a device-wide barrier, every workgroup reduces the (few hundred) maxima itself and
+// writes s / max.  The tensor is read ONCE and written once -- the algorithmic minimum -- where the two-pass form
+// evaluates the stencil twice (second read from the Infinity Cache) behind three launches.  Same arithmetic in the same
+// order as WALK_MAX / WALK_WRITE, and max is exact and order-independent: bit-identical results.
+// The barrier is the cooperative Sinkhorn's (sinkhorn_coop.hip): arrival counter zeroed in front of the launch, agent-
+// scope release / acquire, BOUNDED polling -- if the workgroups were not all resident (the host checks occupancy x CUs
+// before choosing this mode) the poll gives up and the launch writes NaN, never a plausible number.
+struct WalkCtrl { unsigned bar; int abort_flag; };
+constexpr unsigned WALK_SPIN_LIMIT = 1u << 20;
 
 struct WalkArgs {
     const float* in;       // forward: input; adjoint: incoming gradient
@@ -355,6 +379,9 @@ struct WalkArgs {
     float* blockmax;       // WALK_MAX
     const float* mx;       // WALK_WRITE / WALK_ADJX: device scalar, the tensor maximum
     const float* res;      // WALK_ADJX: {sum gout*out, #ties}
+    WalkCtrl* ctrl;        // WALK_COOP: barrier words (zeroed in front of the launch)
+    float* mx_out;         // WALK_COOP, WALK_WRITE with nblk > 0: the tensor maximum is written here
+    int nblk;              // WALK_WRITE: > 0 = reduce blockmax[0, nblk) (the preceding WALK_MAX launch's) instead of reading mx
     int L;                 // axis length
     int64_t S;             // axis stride in floats
     int64_t inner;         // S / VW pieces per axis-stride block
@@ -374,6 +401,7 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
     typedef typename WalkVec<VW>::type V;
     constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX;
     __shared__ float red[16];
+    __shared__ int coop_flag;
     const int L = a.L;
     const int64_t S = a.S;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -382,7 +410,7 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
     const int64_t off = (g / a.inner) * L * S + (g % a.inner) * VW;
     const float* src = a.in + off;
     float m = 1.f, corr = 0.f;
-    if (MODE == WALK_WRITE || MODE == WALK_ADJX) m = a.mx[0];
+    if ((MODE == WALK_WRITE && a.nblk <= 0) || MODE == WALK_ADJX) m = a.mx[0];
     if (MODE == WALK_ADJX) corr = a.res[1] > 0.f ? a.res[0] / (m * a.res[1]) : 0.f;
     V x[LMAX];
 #pragma unroll
@@ -395,6 +423,14 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
             for (int c = 0; c < VW; ++c) vat<VW>(x[p], c) = vat<VW>(x[p], c) / m - (vat<VW>(of, c) == 1.0f ? corr : 0.f);
         }
     }
+    if (MODE == WALK_WRITE && a.nblk > 0) {
+        // every workgroup reduces the preceding launch's block maxima itself, under its own line loads: the separate
+        // single-workgroup reduction launch between the two passes (4.7 us at configs[1]) is gone
+        float v = -FLT_MAX;
+        for (int i = threadIdx.x; i < a.nblk; i += 256) v = fmaxf(v, a.blockmax[i]);
+        m = block_max(v, red);
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.mx_out[0] = m;
+    }
     V zero;
 #pragma unroll
     for (int c = 0; c < VW; ++c) vat<VW>(zero, c) = 0.f;
@@ -405,6 +441,7 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
         else win[j] = (j < R) ? zero : ((j - R < L) ? x[j - R] : zero);    // nothing before 0 / after L-1
     }
     float vmax = -FLT_MAX;
+    V y[MODE == WALK_COOP ? LMAX : 1];  // WALK_COOP: the smoothed line stays in registers across the device-wide barrier
 #pragma unroll
     for (int p = 0; p < LMAX; ++p) {
         const bool live = p < L;        // uniform
@@ -430,11 +467,34 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
                 acc = __builtin_elementwise_fma(wv, win[k + R], acc);
             }
         }
-        if (MODE == WALK_MAX) {
+        if constexpr (MODE == WALK_RAW_TW && VW == 4) {
+            const int pc = (int)(g % a.inner);
+            const bool first = pc == 0, last = pc == (int)a.inner - 1;
+            float v[12];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[4 + c] = vat<VW>(acc, c);
+                v[c] = from_prev_lane(v[4 + c]);
+                v[8 + c] = from_next_lane(v[4 + c]);
+            }
+            // mirrored values: x[-j] = x[j] (j = 1..4), x[W-1+j] = x[W-1-j]
+            const float m4 = v[8], m4b = v[3];               // x[4] resp. x[W-5] as seen from the first / last piece
+            v[3] = first ? v[5] : v[3]; v[2] = first ? v[6] : v[2]; v[1] = first ? v[7] : v[1]; v[0] = first ? m4 : v[0];
+            v[8] = last ? v[6] : v[8]; v[9] = last ? v[5] : v[9]; v[10] = last ? v[4] : v[10]; v[11] = last ? m4b : v[11];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float o = 0.f;
+#pragma unroll
+                for (int k = -R; k <= R; ++k) o = fmaf(a.tp.w[k + R], v[4 + j + k], o);
+                vat<VW>(acc, j) = o;
+            }
+        }
+        if (MODE == WALK_MAX || MODE == WALK_COOP) {
             float mx = vat<VW>(acc, 0);
 #pragma unroll
             for (int c = 1; c < VW; ++c) mx = fmaxf(mx, vat<VW>(acc, c));
             vmax = live ? fmaxf(vmax, mx) : vmax;
+            if (MODE == WALK_COOP) y[MODE == WALK_COOP ? p : 0] = acc;
         } else {
             if (MODE == WALK_WRITE) {
 #pragma unroll
@@ -461,6 +521,42 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
     if (MODE == WALK_MAX && a.blockmax) {
         const float bm = block_max(ok ? vmax : -FLT_MAX, red);
         if (threadIdx.x == 0) a.blockmax[blockIdx.x] = bm;
+    }
+    if (MODE == WALK_COOP) {
+        const float bm = block_max(ok ? vmax : -FLT_MAX, red);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&a.blockmax[blockIdx.x], bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(&a.ctrl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            int ab = 0;
+            while (__hip_atomic_load(&a.ctrl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                ab = __hip_atomic_load(&a.ctrl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ab) break;
+                if (++spins > WALK_SPIN_LIMIT) {
+                    __hip_atomic_store(&a.ctrl->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ab = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            coop_flag = ab;
+        }
+        __syncthreads();
+        float mall = -FLT_MAX;
+        for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
+            mall = fmaxf(mall, __hip_atomic_load(&a.blockmax[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        mall = block_max(mall, red);
+        if (coop_flag) mall = NAN;                       // aborted barrier: not a result
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.mx_out[0] = mall;
+#pragma unroll
+        for (int p = 0; p < LMAX; ++p) {
+            V o = y[MODE == WALK_COOP ? p : 0];
+#pragma unroll
+            for (int c = 0; c < VW; ++c) vat<VW>(o, c) = vat<VW>(o, c) / mall;
+            if (ok && p < L) *reinterpret_cast<V*>(a.out + off + (int64_t)p * S) = o;
+        }
     }
 }
 
@@ -545,6 +641,7 @@ static WalkPlan walk_plan(int L, int64_t S, bool two_inputs, const void* p0, con
     pl.lmax = L <= 32 ? 32 : 64;
     // registers: LMAX x VW floats for the line (twice that in flight while two tensors are being read)
     int vw = (pl.lmax == 32) ? (two_inputs ? 2 : 4) : (two_inputs ? 1 : 2);
+    if (const char* e = getenv("KCCOT_SMOOTH_VW")) { const int v = atoi(e); if ((v == 1 || v == 2) && v < vw) vw = v; }   // tuning knob
     while (vw > 1 && (S % vw != 0 || (uintptr_t)p0 % (4 * vw) || (uintptr_t)p1 % (4 * vw) || (uintptr_t)p2 % (4 * vw))) vw >>= 1;
     pl.vw = vw;
     return pl;
@@ -569,10 +666,54 @@ static int launch_walk(int mode, WalkArgs wa, int radius, int64_t numel, WalkPla
         case WALK_WRITE: KCCOT_WALK_MODE(WALK_WRITE); break;
         case WALK_RAW: KCCOT_WALK_MODE(WALK_RAW); break;
         case WALK_ADJ: KCCOT_WALK_MODE(WALK_ADJ); break;
+        case WALK_COOP: KCCOT_WALK_MODE(WALK_COOP); break;
+        case WALK_RAW_TW: KCCOT_WALK_MODE(WALK_RAW_TW); break;
         default: KCCOT_WALK_MODE(WALK_ADJX); break;
     }
 #undef KCCOT_WALK_MODE
     return launch_status("smooth_walk");
+}
+
+// How many 256-thread workgroups of the WALK_COOP instantiation (radius, plan) the device holds at once: CU count x
+// occupancy, three quarters of it offered (a co-running kernel must not turn a legal launch into a bounded-poll abort);
+// KCCOT_SMOOTH_COOP_MAX_WG=<n> overrides (tests: force the two-pass form by capacity), KCCOT_SMOOTH_NO_COOP=1 disables.
+template <int R>
+static int walk_coop_occupancy(WalkPlan pl) {
+    int per_cu = 0;
+    hipError_t e;
+    if (pl.lmax == 32) {
+        if (pl.vw == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_walk<R, 32, 4, WALK_COOP>, 256, 0);
+        else if (pl.vw == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_walk<R, 32, 2, WALK_COOP>, 256, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_walk<R, 32, 1, WALK_COOP>, 256, 0);
+    } else {
+        if (pl.vw == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_walk<R, 64, 2, WALK_COOP>, 256, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_walk<R, 64, 1, WALK_COOP>, 256, 0);
+    }
+    return e == hipSuccess ? per_cu : 0;
+}
+
+// opt-in (KCCOT_SMOOTH_COOP=1): measured at configs[1] the single launch is SLOWER than the two passes (22.7 us + 4.6 us
+// for zeroing its barrier word against 8.3 + 12.5 us): its phases -- load, stencil, barrier (two memory-side round
+// trips), divide, store -- run one after the other on every CU at once, where the passes overlap them across waves.
+static bool walk_coop_wanted() {
+    const char* e = getenv("KCCOT_SMOOTH_COOP");
+    return e && atoi(e) == 1;
+}
+
+static bool walk_coop_fits(int radius, WalkPlan pl, int64_t nwg) {
+    if (const char* e = getenv("KCCOT_SMOOTH_COOP_MAX_WG")) return nwg <= atoi(e);
+    static int cached[64][2][2][3];      // [device][radius 3/4][lmax 32/64][vw 1/2/4]
+    static bool have[64][2][2][3];
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    const int ri = radius == 3 ? 0 : 1, li = pl.lmax == 32 ? 0 : 1, vi = pl.vw == 4 ? 2 : (pl.vw == 2 ? 1 : 0);
+    if (!have[dev][ri][li][vi]) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        const int occ = radius == 3 ? walk_coop_occupancy<3>(pl) : walk_coop_occupancy<4>(pl);
+        cached[dev][ri][li][vi] = (int)((long long)cus * occ * 3 / 4);
+        have[dev][ri][li][vi] = true;
+    }
+    return nwg <= cached[dev][ri][li][vi];
 }
 
 // sum(gout * out) and #(out == 1) with wide grid-stride loads (the per-element form above launches
@@ -699,9 +840,13 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
             wa.L = T; wa.S = WC;
             if (three) {
                 // T: in -> out (raw);  W: out -> tmp (raw, LDS plane kernel: the axis is contiguous);  H: tmp -> out
-                wa.in = in; wa.out = out;
-                if ((rc = launch_walk(WALK_RAW, wa, radius, n, pt, st))) return rc;
-                if (w1) {
+                // -- or T and W in one launch, in -> tmp (WALK_RAW_TW), when a row of W is W/4 lanes of a wave
+                const int W4 = W >> 2;
+                const bool tw = w1 && pt.vw == 4 && W4 <= 64 && (W4 & (W4 - 1)) == 0 && !getenv("KCCOT_SMOOTH_NO_TW");
+                wa.in = in; wa.out = tw ? tmp : out;
+                if ((rc = launch_walk(tw ? WALK_RAW_TW : WALK_RAW, wa, radius, n, pt, st))) return rc;
+                if (tw) {
+                } else if (w1) {
                     if ((rc = launch_w1(out, tmp, n, W, radius, false, tp, st))) return rc;
                 } else {
                     if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x3f800000, 1, st) != hipSuccess)
@@ -715,14 +860,29 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
                 wa.L = H; wa.S = (int64_t)T * WC;
             }
             wa.in = last_in;
+            const int64_t coop_wgs = (n / wa.L / last.vw + 255) / 256;
+            if (!ext && !nodiv && walk_coop_wanted() && walk_coop_fits(radius, last, coop_wgs)) {
+                // maxima + division in one launch, the smoothed lines held in registers across a device-wide barrier
+                WalkCtrl* ctrl = reinterpret_cast<WalkCtrl*>(one + 16);
+                if (hipMemsetAsync(ctrl, 0, sizeof(WalkCtrl), st) != hipSuccess)
+                    return fail(KCCOT_EINVAL, "smooth_fwd: memset failed");
+                wa.out = out; wa.blockmax = bmax; wa.ctrl = ctrl; wa.mx_out = max_inout;
+                return launch_walk(WALK_COOP, wa, radius, n, last, st);
+            }
+            wa.nblk = 0;
             if (!ext) {
                 wa.out = nullptr; wa.blockmax = bmax;
                 if ((rc = launch_walk(WALK_MAX, wa, radius, n, last, st))) return rc;
                 const int64_t nblk = (n / wa.L / last.vw + 255) / 256;
-                hipLaunchKernelGGL(reduce_blockmax, dim3(1), dim3(1024), 0, st, (const float*)bmax, nblk, max_inout);
-                if ((rc = launch_status("reduce_blockmax"))) return rc;
+                if (!nodiv && nblk <= 4096) {
+                    wa.nblk = (int)nblk;      // the writing pass reduces the block maxima itself (and stores the maximum)
+                } else {
+                    hipLaunchKernelGGL(reduce_blockmax, dim3(1), dim3(1024), 0, st, (const float*)bmax, nblk, max_inout);
+                    if ((rc = launch_status("reduce_blockmax"))) return rc;
+                }
             }
-            wa.out = out; wa.blockmax = nullptr; wa.mx = max_inout;
+            wa.out = out; wa.mx = max_inout; wa.mx_out = max_inout;
+            if (wa.nblk == 0) wa.blockmax = nullptr;
             return launch_walk(nodiv ? WALK_RAW : WALK_WRITE, wa, radius, n, last, st);   // NO_DIVIDE: the raw sums
         }
     }

@@ -171,3 +171,75 @@ def test_hip_smoothing_random_shapes_against_the_pinned_oracle():
             (gd,) = torch.autograd.grad(od, xd, g.cpu().double())
             np.testing.assert_allclose(gx.cpu().numpy(), gd.numpy(), rtol=0, atol=2e-4 * float(gd.abs().max()),
                                        err_msg=str((shape, ksize)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 64, 30, 64, 1), (8, 16, 12, 16, 3), (3, 9, 7, 10, 2), (2, 40, 33, 12, 1)])
+def test_single_launch_smoothing_equals_the_two_pass_form(shape, monkeypatch):
+    """KCCOT_SMOOTH_COOP=1 (opt-in: measured slower than the two passes) runs the final stage as ONE
+    launch -- the smoothed lines stay in registers across a device-wide barrier, the workgroups exchange their maxima and
+    write s / max (WALK_COOP) -- when the tensor fits the device's register files; a capacity the launch does not fit
+    (KCCOT_SMOOTH_COOP_MAX_WG) falls back.  The default is the two-pass form (maxima; recompute + divide, the block maxima
+    reduced by every workgroup of the second pass).  Same stencil arithmetic, same maximum: outputs and maxima are
+    bit-identical, the maximum of the output is exactly 1."""
+    import torch
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, ptr, check, workspace, stream_of
+    rng = np.random.default_rng(sum(shape))
+    x = torch.from_numpy(rng.random(shape, dtype=np.float32)).cuda()
+    B, H, T, W, C = shape
+    wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+    wst = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    ws = wst.data_ptr()
+    for axes, radius in ((_lib.SMOOTH_T, 3), (_lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W, 3), (_lib.SMOOTH_T, 4),
+                         (_lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W, 4)):
+        outs, maxes = [], []
+        for env in ({}, {"KCCOT_SMOOTH_COOP": "1"}, {"KCCOT_SMOOTH_COOP": "1", "KCCOT_SMOOTH_COOP_MAX_WG": "1"}):
+            for k in ("KCCOT_SMOOTH_COOP", "KCCOT_SMOOTH_COOP_MAX_WG"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            wst.fill_(0x5a)                                # the launch must not depend on what the workspace held
+            o = torch.empty_like(x); m = torch.full((1,), -7.0, device=x.device)
+            check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 1.7, radius, axes, ptr(o), ptr(m), ws, wsb, stream_of(x)), "smooth")
+            torch.cuda.synchronize()
+            outs.append(o); maxes.append(float(m))
+        assert float(outs[0].max()) == 1.0
+        assert maxes[0] == maxes[1] == maxes[2] and np.isfinite(maxes[0])
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (shape, axes, radius)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 64, 30, 64, 1), (3, 9, 7, 8, 1), (2, 12, 32, 16, 1), (5, 7, 11, 32, 1), (1, 10, 9, 128, 1),
+                                   (2, 8, 6, 256, 1), (37, 5, 8, 64, 1)])
+def test_fused_t_and_w_stage_equals_the_two_kernels(shape, monkeypatch):
+    """3-D smoothing, C = 1, W/4 a power of two: the T walk applies the W stencil to every T-smoothed piece before storing it
+    (neighbour pieces = neighbouring lanes' registers, DPP wave shifts) instead of a T kernel and a W kernel with a round
+    trip of the tensor in between (KCCOT_SMOOTH_NO_TW=1).  Same fma order: bit-identical outputs, radius 3 and 4."""
+    import torch
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, ptr, check, stream_of
+    from oracle import smoothing_np as sm
+    rng = np.random.default_rng(sum(shape))
+    v = rng.random(shape, dtype=np.float32)
+    x = torch.from_numpy(v).cuda()
+    B, H, T, W, C = shape
+    wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+    wst = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    axes = _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W
+    for radius in (3, 4):
+        if min(H, T, W) <= radius:
+            continue
+        outs = []
+        for no_tw in (False, True):
+            if no_tw:
+                monkeypatch.setenv("KCCOT_SMOOTH_NO_TW", "1")
+            else:
+                monkeypatch.delenv("KCCOT_SMOOTH_NO_TW", raising=False)
+            o = torch.empty_like(x); m = torch.empty(1, device=x.device)
+            check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 1.7, radius, axes, ptr(o), ptr(m), wst.data_ptr(), wsb, stream_of(x)),
+                  "smooth")
+            torch.cuda.synchronize()
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]), (shape, radius)
+        np.testing.assert_allclose(outs[0].cpu().numpy(), sm.gaussian_convolution3D_separable(v, 1.7, radius), rtol=0, atol=ATOL_3D)

@@ -1,41 +1,27 @@
 #!/usr/bin/env python3
-"""Time KernelSmoothing (fwd and fwd+bwd) at the configs[1] video shape; report HBM fraction.
-Algorithmic bytes per call: one read + one write of the tensor (2*B*K*4)."""
-import json, os, sys, time
+"""Kernel-only timing of KernelSmoothing forward (temporal and 3-D) at a BASELINE shape, HIP events around `reps` calls.
+usage: bench_smooth.py [B H T W C]   env: KCCOT_SMOOTH_COOP=1 (single-launch final stage)"""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from kccotgan_amd.data_utils import KernelSmoothing
-
-shape = (64, 64, 30, 64, 1)
-x = torch.rand(shape, device="cuda")
-ks = KernelSmoothing(6, 6)
-nbytes = x.numel() * 4
-
-
-def timeit(fn, reps=50):
-    for _ in range(5):
-        fn()
+from kccotgan_amd import _lib
+from kccotgan_amd._lib import lib, ptr, check
+B, H, T, W, C = (int(a) for a in sys.argv[1:6]) if len(sys.argv) > 5 else (64, 64, 30, 64, 1)
+x = torch.rand(B, H, T, W, C, device="cuda")
+o = torch.empty_like(x); m = torch.empty(1, device="cuda")
+wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+wst = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+n = x.numel()
+for name, axes in (("temporal", _lib.SMOOTH_T), ("conv3d", _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W)):
+    def run(): check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 5.0, 3, axes, ptr(o), ptr(m), wst.data_ptr(), wsb, None), "smooth")
+    for _ in range(5): run()
     torch.cuda.synchronize()
+    reps = 200
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
-
-
-res = {}
-for name, fn in (("temporal", ks.temporal_convolution), ("3d", ks.gaussian_convolution3D)):
-    us = timeit(lambda: fn(x, 5.0))
-    xg = x.clone().requires_grad_(True)
-    w = torch.rand_like(x)
-
-    def fb():
-        y = fn(xg, 5.0)
-        (g,) = torch.autograd.grad(y, xg, w)
-        return g
-    us_fb = timeit(fb)
-    res[name] = dict(fwd_us=us, fwd_bwd_us=us_fb, fwd_alg_GBs=2 * nbytes / us / 1e3, fwd_hbm_frac=2 * nbytes / us / 1e3 / 8000)
-print(json.dumps(res))
+    for _ in range(reps): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    print("%-8s B=%d %dx%dx%d T=%d: %.1f us  (%.2f TB/s algorithmic = %.3f of 8 TB/s)  max %.6f  COOP=%s" % (
+        name, B, H, W, C, T, us, 8.0 * n / us / 1e6, 8.0 * n / us / 1e6 / 8.0, float(m), os.environ.get("KCCOT_SMOOTH_COOP", "0")))
