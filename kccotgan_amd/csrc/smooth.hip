@@ -615,6 +615,387 @@ __global__ __launch_bounds__(256) void smooth_w1(const float* __restrict__ in, f
     *reinterpret_cast<float4*>(out + gid * 4) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// ---- generic forms: any axis length, any channel count -----------------------------------------------------------
+// smooth_walk keeps a whole line of the axis in registers (L <= 64) and smooth_w1 / WALK_RAW_TW need C == 1; everything
+// else used to fall back to the per-element conv_axis chain (configs[3] shape, C = 3: 3-D forward 2.36 ms).  These two
+// kernels cover what is left at streaming speed, with the same fma order as the specialised ones.
+//
+// smooth_roll: a strided axis of ANY length as a rolling walk.  A thread owns VW contiguous floats of one line, keeps the
+// (2R+1)-deep window in registers and fetches the incoming element x[reflect(p + R + 1)] U = 8 steps ahead.  REFLECT is
+// done on the ADDRESS (the mirrored element is re-read; it was loaded a few steps earlier by the same thread: L1 / L2),
+// so the loop has no special cases and every load is unconditional.  Adjoint: sources outside [0, L) are zero and the
+// position-dependent weights (fold-ins of the mirrored taps near both ends) come from a table in LDS.
+template <int R, int VW, int MODE>
+__global__ __launch_bounds__(256) void smooth_roll(WalkArgs a) {
+    typedef typename WalkVec<VW>::type V;
+    constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX;
+    constexpr int U = 8, NW = 2 * R + 1;
+    extern __shared__ float roll_wt[];      // ADJ: L x NW weights
+    __shared__ float red[16];
+    const int L = a.L;
+    const int64_t S = a.S;
+    if (ADJ) {
+        for (int e = threadIdx.x; e < L * NW; e += 256) {
+            const int p = e / NW, k = e % NW - R;
+            int src; float w;
+            roll_wt[e] = tap<R, true>(a.tp, p, k, L, src, w) ? w : 0.f;
+        }
+        __syncthreads();
+    }
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = gid < a.ncols;
+    const int64_t g = ok ? gid : 0;
+    const int64_t off = (g / a.inner) * L * S + (g % a.inner) * VW;
+    const float* src = a.in + off;
+    float m = 1.f, corr = 0.f;
+    if ((MODE == WALK_WRITE && a.nblk <= 0) || MODE == WALK_ADJX) m = a.mx[0];
+    if (MODE == WALK_ADJX) corr = a.res[1] > 0.f ? a.res[0] / (m * a.res[1]) : 0.f;
+    V zero;
+#pragma unroll
+    for (int c = 0; c < VW; ++c) vat<VW>(zero, c) = 0.f;
+    auto fetch = [&](int q) -> V {
+        int qq = q;
+        if (!ADJ) { qq = qq < 0 ? -qq : qq; qq = qq >= L ? 2 * (L - 1) - qq : qq; }
+        const bool inside = q >= 0 && q < L;
+        qq = qq < 0 ? 0 : (qq > L - 1 ? L - 1 : qq);            // prefetch past the last needed element: any valid address
+        V v = *reinterpret_cast<const V*>(src + (int64_t)qq * S);
+        if (MODE == WALK_ADJX) {
+            const V of = *reinterpret_cast<const V*>(a.out_fwd + off + (int64_t)qq * S);
+#pragma unroll
+            for (int c = 0; c < VW; ++c) vat<VW>(v, c) = vat<VW>(v, c) / m - (vat<VW>(const_cast<V&>(of), c) == 1.0f ? corr : 0.f);
+        }
+        if (ADJ) v = inside ? v : zero;
+        return v;
+    };
+    V win[NW], nxt[U];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) win[j] = fetch(j - R);
+#pragma unroll
+    for (int j = 0; j < U; ++j) nxt[j] = fetch(R + 1 + j);
+    if (MODE == WALK_WRITE && a.nblk > 0) {     // see smooth_walk: the preceding WALK_MAX launch's block maxima
+        float v = -FLT_MAX;
+        for (int i = threadIdx.x; i < a.nblk; i += 256) v = fmaxf(v, a.blockmax[i]);
+        m = block_max(v, red);
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.mx_out[0] = m;
+    }
+    float vmax = -FLT_MAX;
+    for (int p0 = 0; p0 < L; p0 += U) {
+        V cur[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) cur[j] = nxt[j];
+#pragma unroll
+        for (int j = 0; j < U; ++j) nxt[j] = fetch(p0 + U + R + 1 + j);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int p = p0 + j;
+            const bool live = p < L;                // uniform
+            const float* wrow = roll_wt + (live ? p : L - 1) * NW;
+            V acc = zero;
+#pragma unroll
+            for (int k = -R; k <= R; ++k) {
+                const float w = ADJ ? wrow[k + R] : a.tp.w[k + R];
+                if constexpr (VW == 1) acc = fmaf(w, win[k + R], acc);
+                else {
+                    V wv;
+#pragma unroll
+                    for (int c = 0; c < VW; ++c) vat<VW>(wv, c) = w;
+                    acc = __builtin_elementwise_fma(wv, win[k + R], acc);
+                }
+            }
+            if (MODE == WALK_MAX) {
+                float mx = vat<VW>(acc, 0);
+#pragma unroll
+                for (int c = 1; c < VW; ++c) mx = fmaxf(mx, vat<VW>(acc, c));
+                vmax = live ? fmaxf(vmax, mx) : vmax;
+            } else {
+                if (MODE == WALK_WRITE) {
+#pragma unroll
+                    for (int c = 0; c < VW; ++c) vat<VW>(acc, c) = vat<VW>(acc, c) / m;
+                }
+                if (ok && live) *reinterpret_cast<V*>(a.out + off + (int64_t)p * S) = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * R; ++i) win[i] = win[i + 1];
+            win[2 * R] = cur[j];
+        }
+    }
+    if (MODE == WALK_MAX && a.blockmax) {
+        const float bm = block_max(ok ? vmax : -FLT_MAX, red);
+        if (threadIdx.x == 0) a.blockmax[blockIdx.x] = bm;
+    }
+}
+
+// smooth_wrow: the contiguous axis W with C interleaved channels.  A workgroup stages `rpw` rows of W*C floats in LDS
+// (coalesced 16-byte loads when the span allows), then thread t computes outputs t, t + 256, ... of the span: consecutive
+// lanes read consecutive LDS words for every tap (conflict-free) and store consecutive floats.  CC = channel count as a
+// compile-time constant (0 = runtime).  Raw sums (W is never the last stage of the 3-D smoothing); ADJ as in smooth_w1.
+// (A form with the REFLECTed halo materialised in LDS -- no reflection arithmetic in the tap loop -- was measured: faster
+// at C = 1, 59 vs 64 us for the whole 3-D call at configs[1], where smooth_w1 serves anyway, and slower at C = 3, 576 vs
+// 548 us at the configs[3] shape: the extra barrier and LDS cost more than the selects.)
+template <int R, bool ADJ, int CC>
+__global__ __launch_bounds__(256) void smooth_wrow(const float* __restrict__ in, float* __restrict__ out, int64_t nrows, int W,
+                                                   int Crt, int rpw, Taps tp) {
+    extern __shared__ __attribute__((aligned(16))) float wrow_lds[];
+    constexpr int NW = 2 * R + 1;
+    const int C = CC ? CC : Crt;
+    const int WC = W * C, span = rpw * WC;
+    float* wt = wrow_lds + ((span + 3) & ~3);
+    if (ADJ) {
+        for (int e = threadIdx.x; e < W * NW; e += 256) {
+            const int p = e / NW, k = e % NW - R;
+            int src; float w;
+            wt[e] = tap<R, true>(tp, p, k, W, src, w) ? w : 0.f;
+        }
+    }
+    const int64_t row0 = (int64_t)blockIdx.x * rpw;
+    const int rows = (int)((nrows - row0) < rpw ? (nrows - row0) : rpw);
+    const int cnt = rows * WC;
+    const float* src = in + row0 * WC;
+    float* dst = out + row0 * WC;
+    if ((span & 3) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+        for (int e = threadIdx.x * 4; e < cnt; e += 1024) {
+            // cnt % 4 == 0 when the workgroup holds all its rpw rows; the last workgroup may hold fewer
+            if (e + 4 <= cnt) *reinterpret_cast<float4*>(wrow_lds + e) = *reinterpret_cast<const float4*>(src + e);
+            else for (int i = e; i < cnt; ++i) wrow_lds[i] = src[i];
+        }
+    } else {
+        for (int e = threadIdx.x; e < cnt; e += 256) wrow_lds[e] = src[e];
+    }
+    __syncthreads();
+    int r = 0, f = threadIdx.x;                       // output e = r * WC + f
+    while (f >= WC) { f -= WC; ++r; }
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const float* row = wrow_lds + r * WC;
+        const int w = f / C, c = f - w * C;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = -R; k <= R; ++k) {
+            int ws = w + k;
+            if (!ADJ) {
+                ws = ws < 0 ? -ws : ws;
+                ws = ws >= W ? 2 * (W - 1) - ws : ws;
+                acc = fmaf(tp.w[k + R], row[ws * C + c], acc);
+            } else {
+                const float wg = wt[w * NW + k + R];      // 0 where the source does not exist
+                ws = ws < 0 ? 0 : (ws > W - 1 ? W - 1 : ws);
+                acc = fmaf(wg, row[ws * C + c], acc);
+            }
+        }
+        dst[e] = acc;
+        f += 256;
+        while (f >= WC) { f -= WC; ++r; }
+    }
+}
+
+// smooth_tw_plane: the T stage and the W stage of the 3-D smoothing in ONE pass over the tensor, any channel count.
+// The rows of one (b, h) are consecutive in memory (t-major), so a workgroup that stages the whole T x W*C plane of a
+// (b, h) in LDS has both stencils' neighbours at hand: forward = T stencil from buffer A (plane + R REFLECTed rows above
+// and below) into buffer B (rows + R*C REFLECTed columns either side), then the W stencil from B to global memory;
+// adjoint = W^T from A (zero column halo, border weights from a table) into B (zero row halo), then T^T to global.
+// With the halos materialised every tap is a plain LDS read at a fixed offset: no reflection arithmetic in the loops.
+// Same fma order as smooth_walk / smooth_roll followed by smooth_w1 / smooth_wrow (forward: bit-identical).  One read
+// and one write of the tensor instead of two each; configs[3] shape: the W*C = 192 rows do not map onto wave lanes
+// (WALK_RAW_TW needs C == 1), this form does not care.
+template <int R, bool ADJ, int CC>
+__global__ __launch_bounds__(256) void smooth_tw_plane(const float* __restrict__ in, float* __restrict__ out, int T, int W,
+                                                       int Crt, Taps tp) {
+    extern __shared__ __attribute__((aligned(16))) float twp[];
+    constexpr int NW = 2 * R + 1;
+    const int C = CC ? CC : Crt;
+    const int WC = W * C, HC = R * C, pitch = WC + 2 * HC, P = T * WC;
+    // forward: A = (T + 2R) x WC, B = T x pitch;  adjoint: A = T x pitch, B = (T + 2R) x WC
+    const int sizeA = ADJ ? T * pitch : (T + 2 * R) * WC;
+    const int sizeB = ADJ ? (T + 2 * R) * WC : T * pitch;
+    float* A = twp;
+    float* Bf = twp + ((sizeA + 3) & ~3);
+    float* wtT = Bf + ((sizeB + 3) & ~3);
+    float* wtW = wtT + T * NW;
+    const int tid = threadIdx.x;
+    if (ADJ) {
+        for (int e = tid; e < T * NW; e += 256) {
+            int src; float w;
+            wtT[e] = tap<R, true>(tp, e / NW, e % NW - R, T, src, w) ? w : 0.f;
+        }
+        for (int e = tid; e < W * NW; e += 256) {
+            int src; float w;
+            wtW[e] = tap<R, true>(tp, e / NW, e % NW - R, W, src, w) ? w : 0.f;
+        }
+    }
+    const float* src = in + (int64_t)blockIdx.x * P;
+    float* dst = out + (int64_t)blockIdx.x * P;
+    // ---- stage 0: the plane into A (interior), coalesced
+    {
+        const bool v4 = (WC & 3) == 0 && (((uintptr_t)in) & 15) == 0 && (!ADJ || ((pitch | HC) & 3) == 0);
+        if (v4) {
+            int t = 0, f = tid * 4;
+            while (f >= WC) { f -= WC; ++t; }
+            for (int e = tid * 4; e < P; e += 1024) {
+                const float4 x = *reinterpret_cast<const float4*>(src + e);
+                float* d = ADJ ? A + t * pitch + HC + f : A + (t + R) * WC + f;
+                *reinterpret_cast<float4*>(d) = x;
+                f += 1024;
+                while (f >= WC) { f -= WC; ++t; }
+            }
+        } else {
+            int t = 0, f = tid;
+            while (f >= WC) { f -= WC; ++t; }
+            for (int e = tid; e < P; e += 256) {
+                (ADJ ? A + t * pitch + HC + f : A + (t + R) * WC + f)[0] = src[e];
+                f += 256;
+                while (f >= WC) { f -= WC; ++t; }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- halo of A: forward = REFLECTed rows t = -R..-1 and T..T+R-1; adjoint = zero columns
+    if (!ADJ) {
+        for (int e = tid; e < 2 * R * WC; e += 256) {
+            const int hr = e / WC, f = e - hr * WC;                 // halo row 0..2R-1
+            const int t = hr < R ? hr - R : T + (hr - R);           // position
+            const int ts = t < 0 ? -t : 2 * (T - 1) - t;            // reflect
+            A[(t + R) * WC + f] = A[(ts + R) * WC + f];
+        }
+    } else {
+        for (int e = tid; e < T * 2 * HC; e += 256) {
+            const int t = e / (2 * HC), j = e - t * 2 * HC;
+            A[t * pitch + (j < HC ? j : WC + j)] = 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- stage 1: first stencil, A -> B interior
+    {
+        int t = 0, f = tid;
+        while (f >= WC) { f -= WC; ++t; }
+        for (int e = tid; e < P; e += 256) {
+            float acc = 0.f;
+            if (!ADJ) {
+                const float* a = A + (t + R) * WC + f;
+#pragma unroll
+                for (int k = -R; k <= R; ++k) acc = fmaf(tp.w[k + R], a[k * WC], acc);
+                Bf[t * pitch + HC + f] = acc;
+            } else {
+                const float* a = A + t * pitch + HC + f;
+                const float* wr = wtW + (f / C) * NW;
+#pragma unroll
+                for (int k = -R; k <= R; ++k) acc = fmaf(wr[k + R], a[k * C], acc);
+                Bf[(t + R) * WC + f] = acc;
+            }
+            f += 256;
+            while (f >= WC) { f -= WC; ++t; }
+        }
+    }
+    __syncthreads();
+    // ---- halo of B: forward = REFLECTed columns; adjoint = zero rows
+    if (!ADJ) {
+        for (int e = tid; e < T * 2 * HC; e += 256) {
+            const int t = e / (2 * HC), j = e - t * 2 * HC;        // j: 0..HC-1 left, HC..2HC-1 right
+            const int hw = j / C, c = j - hw * C;                   // halo w index 0..2R-1, channel
+            const int w = hw < R ? hw - R : W + (hw - R);
+            const int ws = w < 0 ? -w : 2 * (W - 1) - w;
+            Bf[t * pitch + HC + w * C + c] = Bf[t * pitch + HC + ws * C + c];
+        }
+    } else {
+        for (int e = tid; e < 2 * R * WC; e += 256) {
+            const int hr = e / WC, f = e - hr * WC;
+            Bf[(hr < R ? hr : T + hr) * WC + f] = 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- stage 2: second stencil, B -> global
+    {
+        int t = 0, f = tid;
+        while (f >= WC) { f -= WC; ++t; }
+        for (int e = tid; e < P; e += 256) {
+            float acc = 0.f;
+            if (!ADJ) {
+                const float* b = Bf + t * pitch + HC + f;
+#pragma unroll
+                for (int k = -R; k <= R; ++k) acc = fmaf(tp.w[k + R], b[k * C], acc);
+            } else {
+                const float* b = Bf + (t + R) * WC + f;
+                const float* wr = wtT + t * NW;
+#pragma unroll
+                for (int k = -R; k <= R; ++k) acc = fmaf(wr[k + R], b[k * WC], acc);
+            }
+            dst[e] = acc;
+            f += 256;
+            while (f >= WC) { f -= WC; ++t; }
+        }
+    }
+}
+
+static size_t tw_plane_lds(int T, int W, int C, int radius, bool adjoint) {
+    const size_t WC = (size_t)W * C, pitch = WC + 2 * (size_t)radius * C;
+    const size_t a = adjoint ? T * pitch : (T + 2 * (size_t)radius) * WC;
+    const size_t b = adjoint ? (T + 2 * (size_t)radius) * WC : T * pitch;
+    return (((a + 3) & ~(size_t)3) + ((b + 3) & ~(size_t)3) + (adjoint ? (size_t)(T + W) * (2 * radius + 1) : 0)) * sizeof(float);
+}
+
+static bool tw_plane_eligible(int T, int W, int C, int radius, bool adjoint) {
+    // opt-in (KCCOT_SMOOTH_TWPLANE=1): measured at the configs[3] shape the forward gains 5 % (523 vs 548 us) and the
+    // adjoint LOSES 55 % (1077 vs 695 us) against the separate stages -- three scalar LDS loops per element
+    const char* e = getenv("KCCOT_SMOOTH_TWPLANE");
+    if (!(e && atoi(e) == 1)) return false;
+    return (radius == 3 || radius == 4) && T > radius && W > radius && tw_plane_lds(T, W, C, radius, adjoint) <= 156 * 1024;
+}
+
+static int launch_tw_plane(const float* in, float* out, int64_t n, int T, int W, int C, int radius, bool adjoint, const Taps& tp,
+                           hipStream_t st) {
+    const size_t lds = tw_plane_lds(T, W, C, radius, adjoint);
+    const dim3 grid((unsigned)(n / ((int64_t)T * W * C)));
+#define KCCOT_TWP(RR, AA, CCC)                                                                                         \
+    do {                                                                                                               \
+        static bool big_done = false;                                                                                  \
+        if (lds > 64 * 1024 && !big_done) {                                                                            \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_tw_plane<RR, AA, CCC>),                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)             \
+                return fail(KCCOT_EUNSUPPORTED, "smooth_tw_plane: cannot raise the dynamic LDS limit");                \
+            big_done = true;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL((smooth_tw_plane<RR, AA, CCC>), grid, dim3(256), lds, st, in, out, T, W, C, tp);            \
+    } while (0)
+#define KCCOT_TWP_C(RR, AA)                                                                     \
+    switch (C) { case 1: KCCOT_TWP(RR, AA, 1); break; case 2: KCCOT_TWP(RR, AA, 2); break;      \
+                 case 3: KCCOT_TWP(RR, AA, 3); break; case 4: KCCOT_TWP(RR, AA, 4); break;      \
+                 default: KCCOT_TWP(RR, AA, 0); break; }
+    if (radius == 3) { if (adjoint) { KCCOT_TWP_C(3, true) } else { KCCOT_TWP_C(3, false) } }
+    else { if (adjoint) { KCCOT_TWP_C(4, true) } else { KCCOT_TWP_C(4, false) } }
+#undef KCCOT_TWP_C
+#undef KCCOT_TWP
+    return launch_status("smooth_tw_plane");
+}
+
+// rows per workgroup (~16 KB of LDS); 0 = the row does not fit (W * C > 16384)
+static int wrow_rpw(int W, int C) {
+    const int64_t WC = (int64_t)W * C;
+    if (WC > 12288) return 0;
+    const int rpw = (int)(4096 / WC);
+    return rpw < 1 ? 1 : rpw;
+}
+
+static int launch_wrow(const float* in, float* out, int64_t n, int W, int C, int radius, bool adjoint, const Taps& tp,
+                       hipStream_t st) {
+    const int rpw = wrow_rpw(W, C);
+    const int64_t nrows = n / ((int64_t)W * C);
+    const dim3 grid((unsigned)((nrows + rpw - 1) / rpw));
+    const size_t lds = ((size_t)((rpw * W * C + 3) & ~3) + (adjoint ? (size_t)W * (2 * radius + 1) : 0)) * sizeof(float);
+#define KCCOT_WROW(RR, AA, CCC) hipLaunchKernelGGL((smooth_wrow<RR, AA, CCC>), grid, dim3(256), lds, st, in, out, nrows, W, C, rpw, tp)
+#define KCCOT_WROW_C(RR, AA)                                                                      \
+    switch (C) { case 1: KCCOT_WROW(RR, AA, 1); break; case 2: KCCOT_WROW(RR, AA, 2); break;      \
+                 case 3: KCCOT_WROW(RR, AA, 3); break; case 4: KCCOT_WROW(RR, AA, 4); break;      \
+                 default: KCCOT_WROW(RR, AA, 0); break; }
+    if (radius == 3) { if (adjoint) { KCCOT_WROW_C(3, true) } else { KCCOT_WROW_C(3, false) } }
+    else { if (adjoint) { KCCOT_WROW_C(4, true) } else { KCCOT_WROW_C(4, false) } }
+#undef KCCOT_WROW_C
+#undef KCCOT_WROW
+    return launch_status("smooth_wrow");
+}
+
+static bool wrow_eligible(int W, int C, int radius) {
+    return (radius == 3 || radius == 4) && wrow_rpw(W, C) > 0 && W > radius &&
+           ((size_t)wrow_rpw(W, C) * W * C + (size_t)W * (2 * radius + 1) + 4) * sizeof(float) <= 64 * 1024;
+}
+
 static bool w1_eligible(int W, int C, int radius, const void* a, const void* b) {
     return C == 1 && (radius == 3 || radius == 4) && W % 4 == 0 && W >= 8 && W <= 128 &&
            (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0;
@@ -672,6 +1053,60 @@ static int launch_walk(int mode, WalkArgs wa, int radius, int64_t numel, WalkPla
     }
 #undef KCCOT_WALK_MODE
     return launch_status("smooth_walk");
+}
+
+template <int R, int MODE>
+static void launch_roll_r(const WalkArgs& wa, int vw, hipStream_t st) {
+    const dim3 grid((unsigned)((wa.ncols + 255) / 256));
+    constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX;
+    const size_t lds = ADJ ? (size_t)wa.L * (2 * R + 1) * sizeof(float) : 0;
+    if (vw == 4) hipLaunchKernelGGL((smooth_roll<R, 4, MODE>), grid, dim3(256), lds, st, wa);
+    else if (vw == 2) hipLaunchKernelGGL((smooth_roll<R, 2, MODE>), grid, dim3(256), lds, st, wa);
+    else hipLaunchKernelGGL((smooth_roll<R, 1, MODE>), grid, dim3(256), lds, st, wa);
+}
+
+static int launch_roll(int mode, WalkArgs wa, int radius, int64_t numel, int vw, hipStream_t st) {
+    wa.inner = wa.S / vw;
+    wa.ncols = numel / wa.L / vw;
+#define KCCOT_ROLL_MODE(M) do { if (radius == 3) launch_roll_r<3, M>(wa, vw, st); else launch_roll_r<4, M>(wa, vw, st); } while (0)
+    switch (mode) {
+        case WALK_MAX: KCCOT_ROLL_MODE(WALK_MAX); break;
+        case WALK_WRITE: KCCOT_ROLL_MODE(WALK_WRITE); break;
+        case WALK_RAW: KCCOT_ROLL_MODE(WALK_RAW); break;
+        case WALK_ADJ: KCCOT_ROLL_MODE(WALK_ADJ); break;
+        case WALK_ADJX: KCCOT_ROLL_MODE(WALK_ADJX); break;
+        default: return fail(KCCOT_EINVAL, "smooth: mode %d has no rolling form", mode);
+    }
+#undef KCCOT_ROLL_MODE
+    return launch_status("smooth_roll");
+}
+
+// How one strided axis is walked: AXIS_LINE = smooth_walk (the line in registers, L <= 64), AXIS_ROLL = smooth_roll (any L),
+// AXIS_NONE = neither (radius other than 3 / 4, or an adjoint weight table that does not fit LDS): the caller falls back to
+// the per-element chain.  KCCOT_SMOOTH_GENERIC=1 takes the rolling form wherever it exists (tests, A/B).
+enum { AXIS_NONE = 0, AXIS_LINE = 1, AXIS_ROLL = 2 };
+static bool smooth_generic() {
+    const char* e = getenv("KCCOT_SMOOTH_GENERIC");
+    return e && atoi(e) == 1;
+}
+struct AxisPlan { int kind; WalkPlan wp; int vw; };
+
+static AxisPlan axis_plan(int L, int64_t S, bool two_inputs, bool adjoint, int radius, const void* p0, const void* p1,
+                          const void* p2) {
+    AxisPlan ap{AXIS_NONE, WalkPlan{0, 0}, 0};
+    if (radius != 3 && radius != 4) return ap;
+    ap.wp = walk_plan(L, S, two_inputs, p0, p1, p2);
+    if (ap.wp.vw > 0 && !smooth_generic()) { ap.kind = AXIS_LINE; ap.vw = ap.wp.vw; return ap; }
+    if (adjoint && (size_t)L * (2 * radius + 1) * sizeof(float) > 48 * 1024) return ap;
+    int vw = two_inputs ? 2 : 4;
+    while (vw > 1 && (S % vw != 0 || (uintptr_t)p0 % (4 * vw) || (uintptr_t)p1 % (4 * vw) || (uintptr_t)p2 % (4 * vw))) vw >>= 1;
+    ap.kind = AXIS_ROLL; ap.vw = vw;
+    return ap;
+}
+
+static int launch_axis(int mode, const WalkArgs& wa, int radius, int64_t numel, const AxisPlan& ap, hipStream_t st) {
+    if (ap.kind == AXIS_LINE) return launch_walk(mode, wa, radius, numel, ap.wp, st);
+    return launch_roll(mode, wa, radius, numel, ap.vw, st);
 }
 
 // How many 256-thread workgroups of the WALK_COOP instantiation (radius, plan) the device holds at once: CU count x
@@ -829,25 +1264,35 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
         const int64_t WC = (int64_t)W * C;
         const bool three = axes != KCCOT_SMOOTH_T;
         // the last stage runs twice (maxima, then recompute + write s / max); earlier stages write raw sums
-        const WalkPlan pt = walk_plan(T, WC, false, in, out, three ? tmp : out);
-        const WalkPlan ph = three ? walk_plan(H, (int64_t)T * WC, false, tmp, out, out) : WalkPlan{1, 32};
-        const bool w1 = three && w1_eligible(W, C, radius, out, tmp);
-        if (pt.vw > 0 && ph.vw > 0 && (!three || w1 || plane_eligible(T, W, C, radius, 1))) {
+        const AxisPlan pt = axis_plan(T, WC, false, false, radius, in, out, three ? tmp : out);
+        const AxisPlan ph = three ? axis_plan(H, (int64_t)T * WC, false, false, radius, tmp, out, out) : AxisPlan{AXIS_LINE, WalkPlan{1, 32}, 1};
+        const bool w1 = three && w1_eligible(W, C, radius, out, tmp) && !smooth_generic();
+        const bool wplane = three && !w1 && plane_eligible(T, W, C, radius, 1) && !smooth_generic();
+        const bool wrow = three && !w1 && !wplane && wrow_eligible(W, C, radius);
+        if (pt.kind != AXIS_NONE && ph.kind != AXIS_NONE && (!three || w1 || wplane || wrow || tw_plane_eligible(T, W, C, radius, false))) {
             WalkArgs wa{};
             wa.tp = tp;
             const float* last_in = in;
-            WalkPlan last = pt;
+            AxisPlan last = pt;
             wa.L = T; wa.S = WC;
             if (three) {
-                // T: in -> out (raw);  W: out -> tmp (raw, LDS plane kernel: the axis is contiguous);  H: tmp -> out
+                // T: in -> out (raw);  W: out -> tmp (raw; the axis is contiguous: smooth_w1 / LDS rows);  H: tmp -> out
                 // -- or T and W in one launch, in -> tmp (WALK_RAW_TW), when a row of W is W/4 lanes of a wave
                 const int W4 = W >> 2;
-                const bool tw = w1 && pt.vw == 4 && W4 <= 64 && (W4 & (W4 - 1)) == 0 && !getenv("KCCOT_SMOOTH_NO_TW");
-                wa.in = in; wa.out = tw ? tmp : out;
-                if ((rc = launch_walk(tw ? WALK_RAW_TW : WALK_RAW, wa, radius, n, pt, st))) return rc;
-                if (tw) {
+                const bool tw = w1 && pt.kind == AXIS_LINE && pt.vw == 4 && W4 <= 64 && (W4 & (W4 - 1)) == 0 && !getenv("KCCOT_SMOOTH_NO_TW");
+                // -- or, for any channel count, with the (b, h) plane staged in LDS (smooth_tw_plane)
+                const bool twp = !tw && tw_plane_eligible(T, W, C, radius, false);
+                if (twp) {
+                    if ((rc = launch_tw_plane(in, tmp, n, T, W, C, radius, false, tp, st))) return rc;
+                } else {
+                    wa.in = in; wa.out = tw ? tmp : out;
+                    if ((rc = launch_axis(tw ? WALK_RAW_TW : WALK_RAW, wa, radius, n, pt, st))) return rc;
+                }
+                if (tw || twp) {
                 } else if (w1) {
                     if ((rc = launch_w1(out, tmp, n, W, radius, false, tp, st))) return rc;
+                } else if (wrow) {
+                    if ((rc = launch_wrow(out, tmp, n, W, C, radius, false, tp, st))) return rc;
                 } else {
                     if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x3f800000, 1, st) != hipSuccess)
                         return fail(KCCOT_EINVAL, "smooth_fwd: memset failed");
@@ -860,30 +1305,29 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
                 wa.L = H; wa.S = (int64_t)T * WC;
             }
             wa.in = last_in;
-            const int64_t coop_wgs = (n / wa.L / last.vw + 255) / 256;
-            if (!ext && !nodiv && walk_coop_wanted() && walk_coop_fits(radius, last, coop_wgs)) {
+            const int64_t last_wgs = (n / wa.L / last.vw + 255) / 256;
+            if (!ext && !nodiv && last.kind == AXIS_LINE && walk_coop_wanted() && walk_coop_fits(radius, last.wp, last_wgs)) {
                 // maxima + division in one launch, the smoothed lines held in registers across a device-wide barrier
                 WalkCtrl* ctrl = reinterpret_cast<WalkCtrl*>(one + 16);
                 if (hipMemsetAsync(ctrl, 0, sizeof(WalkCtrl), st) != hipSuccess)
                     return fail(KCCOT_EINVAL, "smooth_fwd: memset failed");
                 wa.out = out; wa.blockmax = bmax; wa.ctrl = ctrl; wa.mx_out = max_inout;
-                return launch_walk(WALK_COOP, wa, radius, n, last, st);
+                return launch_walk(WALK_COOP, wa, radius, n, last.wp, st);
             }
             wa.nblk = 0;
             if (!ext) {
                 wa.out = nullptr; wa.blockmax = bmax;
-                if ((rc = launch_walk(WALK_MAX, wa, radius, n, last, st))) return rc;
-                const int64_t nblk = (n / wa.L / last.vw + 255) / 256;
-                if (!nodiv && nblk <= 4096) {
-                    wa.nblk = (int)nblk;      // the writing pass reduces the block maxima itself (and stores the maximum)
+                if ((rc = launch_axis(WALK_MAX, wa, radius, n, last, st))) return rc;
+                if (!nodiv && last_wgs <= 4096) {
+                    wa.nblk = (int)last_wgs;      // the writing pass reduces the block maxima itself (and stores the maximum)
                 } else {
-                    hipLaunchKernelGGL(reduce_blockmax, dim3(1), dim3(1024), 0, st, (const float*)bmax, nblk, max_inout);
+                    hipLaunchKernelGGL(reduce_blockmax, dim3(1), dim3(1024), 0, st, (const float*)bmax, last_wgs, max_inout);
                     if ((rc = launch_status("reduce_blockmax"))) return rc;
                 }
             }
             wa.out = out; wa.mx = max_inout; wa.mx_out = max_inout;
             if (wa.nblk == 0) wa.blockmax = nullptr;
-            return launch_walk(nodiv ? WALK_RAW : WALK_WRITE, wa, radius, n, last, st);   // NO_DIVIDE: the raw sums
+            return launch_axis(nodiv ? WALK_RAW : WALK_WRITE, wa, radius, n, last, st);   // NO_DIVIDE: the raw sums
         }
     }
     if (plane_eligible(T, W, C, radius, na) && !nodiv) {
@@ -972,21 +1416,27 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
         const int64_t WC = (int64_t)W * C;
         const bool three = axes != KCCOT_SMOOTH_T;
         // adjoint stages in reverse order; the first one also applies the adjoint of the max-normalisation
-        const WalkPlan ph = three ? walk_plan(H, (int64_t)T * WC, true, gout, out, din) : WalkPlan{1, 32};
-        const WalkPlan pt = walk_plan(T, WC, !three, three ? (const void*)tmp : (const void*)gout, out, din);
-        const bool w1 = three && w1_eligible(W, C, radius, din, tmp);
-        if (pt.vw > 0 && ph.vw > 0 && (!three || w1 || plane_eligible(T, W, C, radius, 1))) {
+        const AxisPlan ph = three ? axis_plan(H, (int64_t)T * WC, true, true, radius, gout, out, din) : AxisPlan{AXIS_LINE, WalkPlan{1, 32}, 1};
+        const AxisPlan pt = axis_plan(T, WC, !three, true, radius, three ? (const void*)tmp : (const void*)gout, out, din);
+        const bool w1 = three && w1_eligible(W, C, radius, din, tmp) && !smooth_generic();
+        const bool wplane = three && !w1 && plane_eligible(T, W, C, radius, 1) && !smooth_generic();
+        const bool wrow = three && !w1 && !wplane && wrow_eligible(W, C, radius);
+        const bool twp = three && tw_plane_eligible(T, W, C, radius, true);
+        if (pt.kind != AXIS_NONE && ph.kind != AXIS_NONE && (!three || w1 || wplane || wrow || twp)) {
             WalkArgs wa{};
             wa.tp = tp; wa.out_fwd = out; wa.mx = max_in; wa.res = res;
             if (!three) {
                 wa.in = gout; wa.out = din; wa.L = T; wa.S = WC;
-                return launch_walk(WALK_ADJX, wa, radius, n, pt, st);
+                return launch_axis(WALK_ADJX, wa, radius, n, pt, st);
             }
             // H^T (+ normalisation adjoint): gout -> din;  W^T: din -> tmp;  T^T: tmp -> din
-            wa.in = gout; wa.out = din; wa.L = H; wa.S = (int64_t)T * WC;
-            if ((rc = launch_walk(WALK_ADJX, wa, radius, n, ph, st))) return rc;
+            wa.in = gout; wa.out = twp ? tmp : din; wa.L = H; wa.S = (int64_t)T * WC;
+            if ((rc = launch_axis(WALK_ADJX, wa, radius, n, ph, st))) return rc;
+            if (twp) return launch_tw_plane(tmp, din, n, T, W, C, radius, true, tp, st);   // W^T and T^T in one pass: tmp -> din
             if (w1) {
                 if ((rc = launch_w1(din, tmp, n, W, radius, true, tp, st))) return rc;
+            } else if (wrow) {
+                if ((rc = launch_wrow(din, tmp, n, W, C, radius, true, tp, st))) return rc;
             } else {
                 float* one = scal + 4;                          // scalar slots behind {dot, ties}: {1, 0, 0}
                 if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x3f800000, 1, st) != hipSuccess ||
@@ -999,7 +1449,7 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
                 if ((rc = launch_plane(pa, radius, true, dim3((H + pa.hseg - 1) / pa.hseg, B), st))) return rc;
             }
             wa.in = tmp; wa.out = din; wa.L = T; wa.S = WC;
-            return launch_walk(WALK_ADJ, wa, radius, n, pt, st);
+            return launch_axis(WALK_ADJ, wa, radius, n, pt, st);
         }
     }
     // The fused adjoint (smooth_plane<R,true>) is correct but measured slower than the per-axis

@@ -243,3 +243,76 @@ def test_fused_t_and_w_stage_equals_the_two_kernels(shape, monkeypatch):
             outs.append(o)
         assert torch.equal(outs[0], outs[1]), (shape, radius)
         np.testing.assert_allclose(outs[0].cpu().numpy(), sm.gaussian_convolution3D_separable(v, 1.7, radius), rtol=0, atol=ATOL_3D)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 16, 12, 16, 1), (2, 9, 30, 64, 1), (3, 20, 7, 8, 1), (2, 64, 30, 64, 1)])
+def test_generic_kernels_equal_the_specialised_ones(shape, monkeypatch):
+    """KCCOT_SMOOTH_GENERIC=1 routes every stage through the any-length / any-channel kernels (smooth_roll, smooth_wrow)
+    that serve the shapes the specialised kernels cannot take (C > 1 on the W axis, axes longer than 64).  On shapes both
+    families accept: same loads, same fma order -> the forward is bit-identical; the adjoint builds its border weights in
+    a different order (table vs in-line folds) and agrees to rounding."""
+    import torch
+    from kccotgan_amd.data_utils import KernelSmoothing
+    rng = np.random.default_rng(sum(shape) + 5)
+    v = rng.random(shape, dtype=np.float32)
+    gr = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda()
+    for ksize in (6, 8):
+        if min(shape[1:4]) <= ksize // 2:
+            continue
+        ks = KernelSmoothing(ksize, ksize)
+        res = {}
+        for mode in ("special", "generic"):
+            if mode == "generic":
+                monkeypatch.setenv("KCCOT_SMOOTH_GENERIC", "1")
+            else:
+                monkeypatch.delenv("KCCOT_SMOOTH_GENERIC", raising=False)
+            x = torch.from_numpy(v).cuda().requires_grad_(True)
+            t = ks.temporal_convolution(x, 2.1)
+            (gt,) = torch.autograd.grad(t, x, gr)
+            c = ks.gaussian_convolution3D(x, 2.1)
+            (gc,) = torch.autograd.grad(c, x, gr)
+            res[mode] = (t.detach(), c.detach(), gt, gc)
+        assert torch.equal(res["special"][0], res["generic"][0]), (shape, ksize, "temporal")
+        assert torch.equal(res["special"][1], res["generic"][1]), (shape, ksize, "3-D")
+        for i in (2, 3):
+            a, b = res["special"][i], res["generic"][i]
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), (shape, ksize, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 8, 12, 16, 3), (2, 9, 30, 64, 3), (2, 5, 7, 10, 2), (1, 6, 9, 33, 1), (2, 7, 48, 128, 3),
+                                   (2, 4, 5, 6, 5), (2, 64, 30, 64, 1)])
+def test_fused_t_w_plane_kernel_equals_the_separate_stages(shape, monkeypatch):
+    """3-D smoothing with the (b, h) plane staged in LDS (smooth_tw_plane: T and W stencils in one pass, any channel count;
+    adjoint: W^T and T^T; opt-in with KCCOT_SMOOTH_TWPLANE=1, measured slower) against the separate per-axis kernels.  Forward: same fma order,
+    bit-identical.  Adjoint: agrees to rounding, and both against the fp64 autograd of the pinned oracle."""
+    import torch
+    from kccotgan_amd.data_utils import KernelSmoothing
+    from oracle import smoothing_torch as st
+    rng = np.random.default_rng(sum(shape) + 11)
+    v = rng.random(shape, dtype=np.float32)
+    gr = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda()
+    for ksize in (6, 8):
+        r = ksize // 2
+        if min(shape[1:4]) <= r:
+            continue
+        ks = KernelSmoothing(ksize, ksize)
+        res = {}
+        for mode in ("plane", "separate"):
+            if mode == "separate":
+                monkeypatch.delenv("KCCOT_SMOOTH_TWPLANE", raising=False)
+                monkeypatch.setenv("KCCOT_SMOOTH_NO_TW", "1")
+            else:
+                monkeypatch.setenv("KCCOT_SMOOTH_TWPLANE", "1")
+                monkeypatch.delenv("KCCOT_SMOOTH_NO_TW", raising=False)
+            x = torch.from_numpy(v).cuda().requires_grad_(True)
+            c = ks.gaussian_convolution3D(x, 1.9)
+            (gc,) = torch.autograd.grad(c, x, gr)
+            res[mode] = (c.detach(), gc)
+        assert torch.equal(res["plane"][0], res["separate"][0]), (shape, ksize)
+        a, b = res["plane"][1], res["separate"][1]
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), (shape, ksize)
+        xd = torch.from_numpy(v).double().requires_grad_(True)
+        (gd,) = torch.autograd.grad(st.smooth(xd, 1.9, r, (2, 1, 3)), xd, gr.cpu().double())
+        np.testing.assert_allclose(a.cpu().numpy(), gd.numpy(), rtol=0, atol=2e-4 * float(gd.abs().max()), err_msg=str((shape, ksize)))
