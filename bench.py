@@ -261,6 +261,42 @@ def single_gpu_configs(G, dev):
     return out
 
 
+def time_smoothing(dev):
+    """KernelSmoothing forward and backward, kernel time with HIP events, at the configs[1]
+    shape and at the one-GPU shapes of the larger BASELINE configs that fit: us per call and the fraction of the HBM
+    roofline at the algorithmic bytes (forward: read + write the tensor once; backward: read gradient and forward
+    output, write the input gradient)."""
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, ptr, check
+    shapes = {"configs[1]": (SHAPE["B"], SHAPE["H"], SHAPE["T"], SHAPE["W"], SHAPE["C"])}
+    for name, c in OTHER_CONFIGS.items():
+        shapes[name] = c[:5]
+    out = {}
+    for name, (B, H, T, W, C) in shapes.items():
+        n = B * H * T * W * C
+        if n * 4 * 5 > 60e9:
+            continue
+        x = torch.rand(B, H, T, W, C, device=dev); g = torch.randn_like(x)
+        o = torch.empty_like(x); d = torch.empty_like(x); m = torch.empty(1, device=dev)
+        wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rec = {"shape_BHTWC": [B, H, T, W, C], "sigma": 5.0, "radius": 3}
+        for key, axes in (("temporal", _lib.SMOOTH_T), ("conv3d", _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W)):
+            fwd = lambda: check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 5.0, 3, axes, ptr(o), ptr(m), ws.data_ptr(), wsb,
+                                                         None), "smooth_fwd")
+            bwd = lambda: check(lib.kccot_smooth_bwd_f32(ptr(g), ptr(o), ptr(m), B, H, T, W, C, 5.0, 3, axes, ptr(d), ws.data_ptr(),
+                                                         wsb, None), "smooth_bwd")
+            reps = 100 if n < 5e7 else 10
+            tf = time_launches(fwd, reps=reps, warm=3)
+            tb = time_launches(bwd, reps=reps, warm=3)
+            rec[key] = {"fwd_us": tf, "bwd_us": tb, "fwd_hbm_frac": 8.0 * n / (tf * 1e-6) / (HBM_PEAK_GBS * 1e9),
+                        "bwd_hbm_frac": 12.0 * n / (tb * 1e-6) / (HBM_PEAK_GBS * 1e9)}
+        out[name] = rec
+        del x, g, o, d, ws
+        torch.cuda.empty_cache()
+    return out
+
+
 def sharded_config(name, rank, world, dev, dist, barrier, steps=5):
     """The batch-sharded step (kccotgan_amd.dist, gather protocol unless KCCOT_DIST_PROTOCOL says otherwise) of the
     BASELINE config that names this GPU count, global batch fixed (strong scaling of that config)."""
@@ -526,6 +562,11 @@ def main():
             sys.stderr.write("bench: configs block failed on rank %d: %r\n" % (rank, e))
         if rank == 0 and cfgs:
             out["configs"] = cfgs
+        if rank == 0 and world == 1:
+            try:
+                out["kernel_smoothing"] = time_smoothing(dev)
+            except Exception as e:
+                sys.stderr.write("bench: kernel_smoothing block failed: %r\n" % (e,))
     if rank == 0 and world == 1:
       try:
         if not args.no_train:

@@ -316,3 +316,45 @@ def test_fused_t_w_plane_kernel_equals_the_separate_stages(shape, monkeypatch):
         xd = torch.from_numpy(v).double().requires_grad_(True)
         (gd,) = torch.autograd.grad(st.smooth(xd, 1.9, r, (2, 1, 3)), xd, gr.cpu().double())
         np.testing.assert_allclose(a.cpu().numpy(), gd.numpy(), rtol=0, atol=2e-4 * float(gd.abs().max()), err_msg=str((shape, ksize)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(256, 64, 30, 64, 3), (64, 128, 48, 128, 3)])
+def test_full_size_smoothing_at_the_large_baseline_shapes(shape):
+    """BASELINE configs[3] (whole batch on one GPU) and configs[4] (one rank's shard of 8) through KernelSmoothing, C = 3:
+    the any-channel / any-length kernels at full size.  Size-independent properties: the maximum of the output is exactly
+    1 and nothing is negative; the stencil does not couple samples, so a 2-sample slab smoothed on its own and divided by
+    the full tensor's maximum (KCCOT_SMOOTH_EXTERNAL_MAX) reproduces those samples of the full result bit for bit; and that
+    slab agrees with the numpy oracle (pinned to the reference by the fixtures above).  Forward and adjoint stay finite."""
+    import torch
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, ptr, check, stream_of
+    from oracle import smoothing_np as sm
+    B, H, T, W, C = shape
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(shape, device="cuda", generator=g)
+    wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    slab = x[3:5].contiguous()
+    wsb2 = int(lib.kccot_smooth_workspace_bytes(2, H, T, W, C))
+    for axes, oracle in ((_lib.SMOOTH_T, sm.temporal_convolution), (_lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W, sm.gaussian_convolution3D_separable)):
+        o = torch.empty_like(x); m = torch.empty(1, device="cuda")
+        check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 5.0, 3, axes, ptr(o), ptr(m), ws.data_ptr(), wsb, stream_of(x)), "fwd")
+        torch.cuda.synchronize()
+        assert float(o.max()) == 1.0 and float(o.min()) >= 0.0 and np.isfinite(float(m))
+        o2 = torch.empty_like(slab); m2 = m.clone()
+        check(lib.kccot_smooth_fwd_f32(ptr(slab), 2, H, T, W, C, 5.0, 3, axes | _lib.SMOOTH_EXTERNAL_MAX, ptr(o2), ptr(m2), ws.data_ptr(),
+                                       wsb2, stream_of(x)), "slab")
+        torch.cuda.synchronize()
+        assert torch.equal(o2, o[3:5])
+        # oracle on the slab: raw sums (its own maximum divided back out), then the full tensor's maximum
+        ref = oracle(slab.cpu().numpy(), 5.0, 3).astype(np.float64)
+        raw = o2.double().cpu().numpy() * float(m)
+        ref_raw = ref * (raw.max() / ref.max())
+        np.testing.assert_allclose(raw, ref_raw, rtol=0, atol=4e-6 * raw.max())
+        gr = torch.randn(shape, device="cuda", generator=g)
+        d = torch.empty_like(x)
+        check(lib.kccot_smooth_bwd_f32(ptr(gr), ptr(o), ptr(m), B, H, T, W, C, 5.0, 3, axes, ptr(d), ws.data_ptr(), wsb, stream_of(x)), "bwd")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(d).all())
+        del o, d, gr
