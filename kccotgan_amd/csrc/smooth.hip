@@ -787,28 +787,31 @@ __global__ __launch_bounds__(256) void smooth_wrow(const float* __restrict__ in,
     }
 }
 
-// smooth_tw_plane: the T stage and the W stage of the 3-D smoothing in ONE pass over the tensor, any channel count.
-// The rows of one (b, h) are consecutive in memory (t-major), so a workgroup that stages the whole T x W*C plane of a
-// (b, h) in LDS has both stencils' neighbours at hand: forward = T stencil from buffer A (plane + R REFLECTed rows above
-// and below) into buffer B (rows + R*C REFLECTed columns either side), then the W stencil from B to global memory;
-// adjoint = W^T from A (zero column halo, border weights from a table) into B (zero row halo), then T^T to global.
-// With the halos materialised every tap is a plain LDS read at a fixed offset: no reflection arithmetic in the loops.
-// Same fma order as smooth_walk / smooth_roll followed by smooth_w1 / smooth_wrow (forward: bit-identical).  One read
-// and one write of the tensor instead of two each; configs[3] shape: the W*C = 192 rows do not map onto wave lanes
-// (WALK_RAW_TW needs C == 1), this form does not care.
+// smooth_tw_plane: the T stage and the W stage of the 3-D smoothing in ONE pass over the tensor, any channel count
+// 1..4 (W*C a multiple of 4).  The rows of one (b, h) are consecutive in memory (t-major), so a workgroup that stages the
+// whole T x W*C plane of a (b, h) in LDS has both stencils' neighbours at hand: forward = T stencil from buffer A (plane
+// + R REFLECTed rows above and below) into buffer B (rows + a REFLECTed column halo either side), then the W stencil from
+// B to global memory; adjoint = W^T from A (zero column halo, border weights from a table) into B (zero row halo), then
+// T^T to global.  With the halos materialised every tap is a plain LDS read at a fixed offset, and everything moves as
+// float4: a thread item is four consecutive floats of a row -- the T stencil is 2R+1 ds_read_b128 at row offsets, the W
+// stencil reads the 4 + 2 R C floats it needs as 2 ceil(R C / 4) + 1 aligned float4s and indexes them statically (C is a
+// template parameter).  Same fma order per output as smooth_walk / smooth_roll followed by smooth_w1 / smooth_wrow
+// (forward: bit-identical).  One read and one write of the tensor instead of two each.
+// (The first version of this kernel walked single floats through three LDS loops and was VALU-bound: forward +5 %,
+// adjoint -55 % against the separate stages at the configs[3] shape.)
 template <int R, bool ADJ, int CC>
 __global__ __launch_bounds__(256) void smooth_tw_plane(const float* __restrict__ in, float* __restrict__ out, int T, int W,
-                                                       int Crt, Taps tp) {
+                                                       Taps tp) {
     extern __shared__ __attribute__((aligned(16))) float twp[];
-    constexpr int NW = 2 * R + 1;
-    const int C = CC ? CC : Crt;
-    const int WC = W * C, HC = R * C, pitch = WC + 2 * HC, P = T * WC;
+    constexpr int NW = 2 * R + 1, C = CC;
+    constexpr int NQ = (R * C + 3) / 4, HP = 4 * NQ;        // halo columns, padded to whole float4s
+    const int WC = W * C, Q = WC >> 2, pitch = WC + 2 * HP, P = T * WC, P4 = T * Q;
     // forward: A = (T + 2R) x WC, B = T x pitch;  adjoint: A = T x pitch, B = (T + 2R) x WC
     const int sizeA = ADJ ? T * pitch : (T + 2 * R) * WC;
     const int sizeB = ADJ ? (T + 2 * R) * WC : T * pitch;
     float* A = twp;
-    float* Bf = twp + ((sizeA + 3) & ~3);
-    float* wtT = Bf + ((sizeB + 3) & ~3);
+    float* Bf = twp + sizeA;
+    float* wtT = Bf + sizeB;
     float* wtW = wtT + T * NW;
     const int tid = threadIdx.x;
     if (ADJ) {
@@ -823,120 +826,125 @@ __global__ __launch_bounds__(256) void smooth_tw_plane(const float* __restrict__
     }
     const float* src = in + (int64_t)blockIdx.x * P;
     float* dst = out + (int64_t)blockIdx.x * P;
+    int t0 = 0, q0 = tid;                                   // this thread's first item (t0, q0); items step by 256
+    while (q0 >= Q) { q0 -= Q; ++t0; }
     // ---- stage 0: the plane into A (interior), coalesced
     {
-        const bool v4 = (WC & 3) == 0 && (((uintptr_t)in) & 15) == 0 && (!ADJ || ((pitch | HC) & 3) == 0);
-        if (v4) {
-            int t = 0, f = tid * 4;
-            while (f >= WC) { f -= WC; ++t; }
-            for (int e = tid * 4; e < P; e += 1024) {
-                const float4 x = *reinterpret_cast<const float4*>(src + e);
-                float* d = ADJ ? A + t * pitch + HC + f : A + (t + R) * WC + f;
-                *reinterpret_cast<float4*>(d) = x;
-                f += 1024;
-                while (f >= WC) { f -= WC; ++t; }
-            }
-        } else {
-            int t = 0, f = tid;
-            while (f >= WC) { f -= WC; ++t; }
-            for (int e = tid; e < P; e += 256) {
-                (ADJ ? A + t * pitch + HC + f : A + (t + R) * WC + f)[0] = src[e];
-                f += 256;
-                while (f >= WC) { f -= WC; ++t; }
-            }
+        int t = t0, q = q0;
+        for (int i = tid; i < P4; i += 256) {
+            const float4 x = reinterpret_cast<const float4*>(src)[i];
+            *reinterpret_cast<float4*>(ADJ ? A + t * pitch + HP + 4 * q : A + (t + R) * WC + 4 * q) = x;
+            q += 256;
+            while (q >= Q) { q -= Q; ++t; }
         }
     }
     __syncthreads();
     // ---- halo of A: forward = REFLECTed rows t = -R..-1 and T..T+R-1; adjoint = zero columns
     if (!ADJ) {
-        for (int e = tid; e < 2 * R * WC; e += 256) {
-            const int hr = e / WC, f = e - hr * WC;                 // halo row 0..2R-1
+        for (int i = tid; i < 2 * R * Q; i += 256) {
+            const int hr = i / Q, q = i - hr * Q;                   // halo row 0..2R-1
             const int t = hr < R ? hr - R : T + (hr - R);           // position
             const int ts = t < 0 ? -t : 2 * (T - 1) - t;            // reflect
-            A[(t + R) * WC + f] = A[(ts + R) * WC + f];
+            *reinterpret_cast<float4*>(A + (t + R) * WC + 4 * q) = *reinterpret_cast<const float4*>(A + (ts + R) * WC + 4 * q);
         }
     } else {
-        for (int e = tid; e < T * 2 * HC; e += 256) {
-            const int t = e / (2 * HC), j = e - t * 2 * HC;
-            A[t * pitch + (j < HC ? j : WC + j)] = 0.f;
+        for (int i = tid; i < T * 2 * NQ; i += 256) {
+            const int t = i / (2 * NQ), j = i - t * 2 * NQ;
+            *reinterpret_cast<float4*>(A + t * pitch + (j < NQ ? 4 * j : WC + 4 * j)) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
+    // the W stencil of four consecutive outputs from a row with halo: x points at the first of them
+    auto wconv = [&](const float* x, int f, float4& o) {
+        float v[4 * (2 * NQ + 1)];
+#pragma unroll
+        for (int j = 0; j < 2 * NQ + 1; ++j) {
+            const float4 p = *reinterpret_cast<const float4*>(x + 4 * (j - NQ));
+            v[4 * j] = p.x; v[4 * j + 1] = p.y; v[4 * j + 2] = p.z; v[4 * j + 3] = p.w;
+        }
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.f;
+            const float* wr = wtW + ((f + j) / C) * NW;     // adjoint only
+#pragma unroll
+            for (int k = -R; k <= R; ++k) acc = fmaf(ADJ ? wr[k + R] : tp.w[k + R], v[HP + j + k * C], acc);
+            r[j] = acc;
+        }
+        o = make_float4(r[0], r[1], r[2], r[3]);
+    };
+    // the T stencil of a float4 column item: x points at row t of a (T + 2R)-row buffer without column halo
+    auto tconv = [&](const float* x, int t, float4& o) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = -R; k <= R; ++k) {
+            const float w = ADJ ? wtT[t * NW + k + R] : tp.w[k + R];
+            const float4 p = *reinterpret_cast<const float4*>(x + k * WC);
+            acc.x = fmaf(w, p.x, acc.x); acc.y = fmaf(w, p.y, acc.y); acc.z = fmaf(w, p.z, acc.z); acc.w = fmaf(w, p.w, acc.w);
+        }
+        o = acc;
+    };
     // ---- stage 1: first stencil, A -> B interior
     {
-        int t = 0, f = tid;
-        while (f >= WC) { f -= WC; ++t; }
-        for (int e = tid; e < P; e += 256) {
-            float acc = 0.f;
+        int t = t0, q = q0;
+        for (int i = tid; i < P4; i += 256) {
+            float4 o;
             if (!ADJ) {
-                const float* a = A + (t + R) * WC + f;
-#pragma unroll
-                for (int k = -R; k <= R; ++k) acc = fmaf(tp.w[k + R], a[k * WC], acc);
-                Bf[t * pitch + HC + f] = acc;
+                tconv(A + (t + R) * WC + 4 * q, t, o);
+                *reinterpret_cast<float4*>(Bf + t * pitch + HP + 4 * q) = o;
             } else {
-                const float* a = A + t * pitch + HC + f;
-                const float* wr = wtW + (f / C) * NW;
-#pragma unroll
-                for (int k = -R; k <= R; ++k) acc = fmaf(wr[k + R], a[k * C], acc);
-                Bf[(t + R) * WC + f] = acc;
+                wconv(A + t * pitch + HP + 4 * q, 4 * q, o);
+                *reinterpret_cast<float4*>(Bf + (t + R) * WC + 4 * q) = o;
             }
-            f += 256;
-            while (f >= WC) { f -= WC; ++t; }
+            q += 256;
+            while (q >= Q) { q -= Q; ++t; }
         }
     }
     __syncthreads();
     // ---- halo of B: forward = REFLECTed columns; adjoint = zero rows
     if (!ADJ) {
-        for (int e = tid; e < T * 2 * HC; e += 256) {
-            const int t = e / (2 * HC), j = e - t * 2 * HC;        // j: 0..HC-1 left, HC..2HC-1 right
+        for (int e = tid; e < T * 2 * R * C; e += 256) {
+            const int t = e / (2 * R * C), j = e - t * 2 * R * C;
             const int hw = j / C, c = j - hw * C;                   // halo w index 0..2R-1, channel
             const int w = hw < R ? hw - R : W + (hw - R);
             const int ws = w < 0 ? -w : 2 * (W - 1) - w;
-            Bf[t * pitch + HC + w * C + c] = Bf[t * pitch + HC + ws * C + c];
+            Bf[t * pitch + HP + w * C + c] = Bf[t * pitch + HP + ws * C + c];
         }
     } else {
-        for (int e = tid; e < 2 * R * WC; e += 256) {
-            const int hr = e / WC, f = e - hr * WC;
-            Bf[(hr < R ? hr : T + hr) * WC + f] = 0.f;
+        for (int i = tid; i < 2 * R * Q; i += 256) {
+            const int hr = i / Q, q = i - hr * Q;
+            *reinterpret_cast<float4*>(Bf + (hr < R ? hr : T + hr) * WC + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
     // ---- stage 2: second stencil, B -> global
     {
-        int t = 0, f = tid;
-        while (f >= WC) { f -= WC; ++t; }
-        for (int e = tid; e < P; e += 256) {
-            float acc = 0.f;
-            if (!ADJ) {
-                const float* b = Bf + t * pitch + HC + f;
-#pragma unroll
-                for (int k = -R; k <= R; ++k) acc = fmaf(tp.w[k + R], b[k * C], acc);
-            } else {
-                const float* b = Bf + (t + R) * WC + f;
-                const float* wr = wtT + t * NW;
-#pragma unroll
-                for (int k = -R; k <= R; ++k) acc = fmaf(wr[k + R], b[k * WC], acc);
-            }
-            dst[e] = acc;
-            f += 256;
-            while (f >= WC) { f -= WC; ++t; }
+        int t = t0, q = q0;
+        for (int i = tid; i < P4; i += 256) {
+            float4 o;
+            if (!ADJ) wconv(Bf + t * pitch + HP + 4 * q, 4 * q, o);
+            else tconv(Bf + (t + R) * WC + 4 * q, t, o);
+            reinterpret_cast<float4*>(dst)[i] = o;
+            q += 256;
+            while (q >= Q) { q -= Q; ++t; }
         }
     }
 }
 
 static size_t tw_plane_lds(int T, int W, int C, int radius, bool adjoint) {
-    const size_t WC = (size_t)W * C, pitch = WC + 2 * (size_t)radius * C;
+    const size_t WC = (size_t)W * C, pitch = WC + 2 * 4 * (((size_t)radius * C + 3) / 4);
     const size_t a = adjoint ? T * pitch : (T + 2 * (size_t)radius) * WC;
     const size_t b = adjoint ? (T + 2 * (size_t)radius) * WC : T * pitch;
-    return (((a + 3) & ~(size_t)3) + ((b + 3) & ~(size_t)3) + (adjoint ? (size_t)(T + W) * (2 * radius + 1) : 0)) * sizeof(float);
+    return (a + b + (adjoint ? (size_t)(T + W) * (2 * radius + 1) : 0)) * sizeof(float);
 }
 
-static bool tw_plane_eligible(int T, int W, int C, int radius, bool adjoint) {
-    // opt-in (KCCOT_SMOOTH_TWPLANE=1): measured at the configs[3] shape the forward gains 5 % (523 vs 548 us) and the
-    // adjoint LOSES 55 % (1077 vs 695 us) against the separate stages -- three scalar LDS loops per element
-    const char* e = getenv("KCCOT_SMOOTH_TWPLANE");
-    if (!(e && atoi(e) == 1)) return false;
-    return (radius == 3 || radius == 4) && T > radius && W > radius && tw_plane_lds(T, W, C, radius, adjoint) <= 156 * 1024;
+static bool tw_plane_eligible(int T, int W, int C, int radius, bool adjoint, const void* p0, const void* p1) {
+    if (const char* e = getenv("KCCOT_SMOOTH_NO_TWPLANE")) if (atoi(e) == 1) return false;
+    // the adjoint form is opt-in (KCCOT_SMOOTH_TWPLANE_BWD=1): its border-weight table reads make it SLOWER than the
+    // separate W^T and T^T stages (configs[3] shape: 741 vs 682 us for the whole 3-D adjoint); forward: 456 vs 545 us
+    if (adjoint) { const char* e = getenv("KCCOT_SMOOTH_TWPLANE_BWD"); if (!(e && atoi(e) == 1)) return false; }
+    return (radius == 3 || radius == 4) && C >= 1 && C <= 4 && ((W * C) & 3) == 0 && T > radius && W > radius &&
+           (((uintptr_t)p0 | (uintptr_t)p1) & 15) == 0 && tw_plane_lds(T, W, C, radius, adjoint) <= 156 * 1024;
 }
 
 static int launch_tw_plane(const float* in, float* out, int64_t n, int T, int W, int C, int radius, bool adjoint, const Taps& tp,
@@ -952,12 +960,11 @@ static int launch_tw_plane(const float* in, float* out, int64_t n, int T, int W,
                 return fail(KCCOT_EUNSUPPORTED, "smooth_tw_plane: cannot raise the dynamic LDS limit");                \
             big_done = true;                                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL((smooth_tw_plane<RR, AA, CCC>), grid, dim3(256), lds, st, in, out, T, W, C, tp);            \
+        hipLaunchKernelGGL((smooth_tw_plane<RR, AA, CCC>), grid, dim3(256), lds, st, in, out, T, W, tp);               \
     } while (0)
 #define KCCOT_TWP_C(RR, AA)                                                                     \
     switch (C) { case 1: KCCOT_TWP(RR, AA, 1); break; case 2: KCCOT_TWP(RR, AA, 2); break;      \
-                 case 3: KCCOT_TWP(RR, AA, 3); break; case 4: KCCOT_TWP(RR, AA, 4); break;      \
-                 default: KCCOT_TWP(RR, AA, 0); break; }
+                 case 3: KCCOT_TWP(RR, AA, 3); break; default: KCCOT_TWP(RR, AA, 4); break; }
     if (radius == 3) { if (adjoint) { KCCOT_TWP_C(3, true) } else { KCCOT_TWP_C(3, false) } }
     else { if (adjoint) { KCCOT_TWP_C(4, true) } else { KCCOT_TWP_C(4, false) } }
 #undef KCCOT_TWP_C
@@ -1269,7 +1276,7 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
         const bool w1 = three && w1_eligible(W, C, radius, out, tmp) && !smooth_generic();
         const bool wplane = three && !w1 && plane_eligible(T, W, C, radius, 1) && !smooth_generic();
         const bool wrow = three && !w1 && !wplane && wrow_eligible(W, C, radius);
-        if (pt.kind != AXIS_NONE && ph.kind != AXIS_NONE && (!three || w1 || wplane || wrow || tw_plane_eligible(T, W, C, radius, false))) {
+        if (pt.kind != AXIS_NONE && ph.kind != AXIS_NONE && (!three || w1 || wplane || wrow || tw_plane_eligible(T, W, C, radius, false, in, tmp))) {
             WalkArgs wa{};
             wa.tp = tp;
             const float* last_in = in;
@@ -1281,7 +1288,7 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
                 const int W4 = W >> 2;
                 const bool tw = w1 && pt.kind == AXIS_LINE && pt.vw == 4 && W4 <= 64 && (W4 & (W4 - 1)) == 0 && !getenv("KCCOT_SMOOTH_NO_TW");
                 // -- or, for any channel count, with the (b, h) plane staged in LDS (smooth_tw_plane)
-                const bool twp = !tw && tw_plane_eligible(T, W, C, radius, false);
+                const bool twp = !tw && tw_plane_eligible(T, W, C, radius, false, in, tmp);
                 if (twp) {
                     if ((rc = launch_tw_plane(in, tmp, n, T, W, C, radius, false, tp, st))) return rc;
                 } else {
@@ -1421,7 +1428,7 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
         const bool w1 = three && w1_eligible(W, C, radius, din, tmp) && !smooth_generic();
         const bool wplane = three && !w1 && plane_eligible(T, W, C, radius, 1) && !smooth_generic();
         const bool wrow = three && !w1 && !wplane && wrow_eligible(W, C, radius);
-        const bool twp = three && tw_plane_eligible(T, W, C, radius, true);
+        const bool twp = three && tw_plane_eligible(T, W, C, radius, true, tmp, din);
         if (pt.kind != AXIS_NONE && ph.kind != AXIS_NONE && (!three || w1 || wplane || wrow || twp)) {
             WalkArgs wa{};
             wa.tp = tp; wa.out_fwd = out; wa.mx = max_in; wa.res = res;

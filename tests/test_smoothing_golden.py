@@ -282,10 +282,10 @@ def test_generic_kernels_equal_the_specialised_ones(shape, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(3, 8, 12, 16, 3), (2, 9, 30, 64, 3), (2, 5, 7, 10, 2), (1, 6, 9, 33, 1), (2, 7, 48, 128, 3),
-                                   (2, 4, 5, 6, 5), (2, 64, 30, 64, 1)])
+                                   (2, 4, 5, 6, 5), (2, 64, 30, 64, 1), (2, 5, 40, 96, 3), (3, 6, 9, 12, 4), (2, 6, 8, 20, 1)])
 def test_fused_t_w_plane_kernel_equals_the_separate_stages(shape, monkeypatch):
     """3-D smoothing with the (b, h) plane staged in LDS (smooth_tw_plane: T and W stencils in one pass, any channel count;
-    adjoint: W^T and T^T; opt-in with KCCOT_SMOOTH_TWPLANE=1, measured slower) against the separate per-axis kernels.  Forward: same fma order,
+    adjoint: W^T and T^T) against the separate per-axis kernels (KCCOT_SMOOTH_NO_TWPLANE=1).  Forward: same fma order,
     bit-identical.  Adjoint: agrees to rounding, and both against the fp64 autograd of the pinned oracle."""
     import torch
     from kccotgan_amd.data_utils import KernelSmoothing
@@ -301,11 +301,12 @@ def test_fused_t_w_plane_kernel_equals_the_separate_stages(shape, monkeypatch):
         res = {}
         for mode in ("plane", "separate"):
             if mode == "separate":
-                monkeypatch.delenv("KCCOT_SMOOTH_TWPLANE", raising=False)
+                monkeypatch.setenv("KCCOT_SMOOTH_NO_TWPLANE", "1")
                 monkeypatch.setenv("KCCOT_SMOOTH_NO_TW", "1")
             else:
-                monkeypatch.setenv("KCCOT_SMOOTH_TWPLANE", "1")
+                monkeypatch.delenv("KCCOT_SMOOTH_NO_TWPLANE", raising=False)
                 monkeypatch.delenv("KCCOT_SMOOTH_NO_TW", raising=False)
+            monkeypatch.setenv("KCCOT_SMOOTH_TWPLANE_BWD", "1")      # the adjoint form is opt-in (measured slower)
             x = torch.from_numpy(v).cuda().requires_grad_(True)
             c = ks.gaussian_convolution3D(x, 1.9)
             (gc,) = torch.autograd.grad(c, x, gr)
