@@ -18,6 +18,43 @@ _gpu_was_live = "torch" in _sys.modules and _sys.modules["torch"].cuda.is_initia
 _os.environ.setdefault(MIOPEN_SWITCH, "0")
 MIOPEN_WORKAROUND_GUARANTEED = (_user_value == "0") or (_user_value is None and not _gpu_was_live)
 
+
+
+def _install_miopen_find_db(force=False):
+    """Ship MIOpen's solver choices for the G/D convolutions of the BASELINE shapes (``miopen_db/*.ufdb.txt``, 30 KB, written
+    by MIOpen itself during one run with its default exhaustive find on an MI355X: tools/bench_train.py).  With it the first
+    training iteration takes seconds instead of ~5 minutes of solver benchmarking, and the steady state is the exhaustive
+    search's (0.94 s per iteration at configs[1]) rather than fast-find's (2.5 s).  The files are copied to a per-user
+    cache directory (MIOpen appends to its user database) and MIOPEN_USER_DB_PATH is pointed there -- unless the user has
+    set that variable, already has a tuned database in MIOpen's default place, sets KCCOT_NO_MIOPEN_DB=1, or the host has
+    no AMD GPU (/dev/kfd).  A database
+    written by another MIOpen version has another file name and is simply not read.  Returns the directory or None."""
+    import shutil
+    if _os.environ.get("KCCOT_NO_MIOPEN_DB") == "1" or "MIOPEN_USER_DB_PATH" in _os.environ:
+        return None
+    if not force and not _os.path.exists("/dev/kfd"):
+        return None                                       # no AMD GPU on this host: nothing will run a convolution
+    try:
+        src = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
+        files = [f for f in _os.listdir(src) if f.endswith(".ufdb.txt")]
+        if not files:
+            return None
+        default_dir = _os.path.join(_os.path.expanduser("~"), ".config", "miopen")
+        if _os.path.isdir(default_dir) and any(f.endswith(".ufdb.txt") for f in _os.listdir(default_dir)):
+            return None                                   # the user's own tuning wins
+        dst = _os.path.join(_os.path.expanduser("~"), ".cache", "kccotgan_amd", "miopen_db")
+        _os.makedirs(dst, exist_ok=True)
+        for f in files:
+            if not _os.path.exists(_os.path.join(dst, f)):
+                shutil.copyfile(_os.path.join(src, f), _os.path.join(dst, f))
+        _os.environ["MIOPEN_USER_DB_PATH"] = dst
+        return dst
+    except OSError:
+        return None
+
+
+MIOPEN_FIND_DB_DIR = None if _gpu_was_live else _install_miopen_find_db()
+
 from . import _lib            # noqa: F401,E402  (loads the HIP library)
 from . import gan_utils       # noqa: F401,E402
 from . import data_utils      # noqa: F401,E402

@@ -1,5 +1,6 @@
 """CPU checks of the PyTorch G/D models and the LR schedule (f2): layer
 stack, tensor layouts and shapes of the reference's gan.py; Keras numerics are parity-unpinned."""
+import os
 import torch
 
 from kccotgan_amd import gan
@@ -157,3 +158,28 @@ def test_shared_adam_counts_two_apply_gradients_per_step_like_keras():
         if step == 0:
             assert torch.equal(a, a0)          # lr(0) = 0: the first network's first update is a no-op
             assert not torch.equal(b, b0)
+
+
+def test_shipped_miopen_find_db_is_installed_for_the_user(tmp_path, monkeypatch):
+    """kccotgan_amd ships MIOpen's solver choices for the G/D convolutions (miopen_db/*.ufdb.txt): at import they are
+    copied to a per-user cache directory and MIOPEN_USER_DB_PATH is pointed there, unless the user has a database of
+    their own or opts out."""
+    import kccotgan_amd
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.delenv("KCCOT_NO_MIOPEN_DB", raising=False)
+    d = kccotgan_amd._install_miopen_find_db(force=True)
+    assert d and d.startswith(str(tmp_path)) and os.environ["MIOPEN_USER_DB_PATH"] == d
+    assert any(f.endswith(".ufdb.txt") for f in os.listdir(d))
+    # an explicit choice of the user is left alone
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
+    assert kccotgan_amd._install_miopen_find_db(force=True) is None and os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("KCCOT_NO_MIOPEN_DB", "1")
+    assert kccotgan_amd._install_miopen_find_db(force=True) is None
+    # a tuned database in MIOpen's default place wins
+    monkeypatch.delenv("KCCOT_NO_MIOPEN_DB")
+    own = tmp_path / ".config" / "miopen"
+    own.mkdir(parents=True)
+    (own / "gfx950100.HIP.x.ufdb.txt").write_text("")
+    assert kccotgan_amd._install_miopen_find_db(force=True) is None
