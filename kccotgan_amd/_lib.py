@@ -122,6 +122,8 @@ def empty_like(t):
 
 
 def _verify_guards(what):
+    if torch.cuda.is_current_stream_capturing():
+        return                      # no synchronisation inside a hipGraph capture: the next eager call verifies
     torch.cuda.synchronize()
     for buf, n in _guards:
         lo, hi = buf[:_GUARD], buf[_GUARD + n:]
