@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs kccotgan_amd/csrc/libkccot_old.so: tools/build_old_lib.sh <commit> (run here, the .so travels with the snapshot)
 # bit-level and timing A/B of two library builds on the loss backward (video gradient kernels)
 set -o pipefail
 OLD=$PWD/kccotgan_amd/csrc/libkccot_old.so

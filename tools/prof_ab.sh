@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs kccotgan_amd/csrc/libkccot_old.so: tools/build_old_lib.sh <commit> (run here, the .so travels with the snapshot)
 # per-kernel average durations of the configs[1] step for two library builds (rocprofv3 --kernel-trace --stats)
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for lib in old new; do
