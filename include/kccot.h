@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KCCOT_VERSION 200          /* 0.2.0 */
+#define KCCOT_VERSION 201          /* 0.2.1 */
 #define KCCOT_EINVAL (-1)          /* bad shape / null pointer / inconsistent arguments      */
 #define KCCOT_EUNSUPPORTED (-2)    /* valid request outside what this build implements       */
 #define KCCOT_EWORKSPACE (-3)      /* workspace too small                                    */
@@ -248,6 +248,21 @@ int kccot_martingale_fwd_f32(const float* M, int B, int T, int J, float lam, flo
                              float* pm_out, kccot_stream_t stream);
 int kccot_martingale_bwd_f32(const float* M, int B, int T, int J, float lam, float sc,
                              const float* gpm, float* dM, kccot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One time step of the ConvLSTM cells of the generator (the reference
+ * uses tf.keras.layers.ConvLSTM2D: gan.py:50-85 encoder, gan.py:194-266 decoder), everything behind
+ * the two convolutions in ONE launch: with g = gx + gh the four gate pre-activations [B,4F,HW]
+ * (gate order i, f, c, o as in Keras; gx = input convolution, gh = recurrent convolution of h_prev),
+ *   i = hard_sigmoid(g_i), f = hard_sigmoid(g_f), cc = tanh(g_c), o = hard_sigmoid(g_o)
+ *   c = f * c_prev + i * cc;  h = o * tanh(c)            hard_sigmoid(x) = clip(0.2 x + 0.5, 0, 1)
+ * c_prev, c_out, h_out: [B,F,HW].  Backward: dh, dc_out (either may be NULL = zero) -> dg [B,4F,HW]
+ * (the gradient of gx AND of gh) and dc_prev; the gates are recomputed from gx + gh. */
+int kccot_convlstm_cell_fwd_f32(const float* gx, const float* gh, const float* c_prev, int B, int F, int HW,
+                                float* c_out, float* h_out, kccot_stream_t stream);
+int kccot_convlstm_cell_bwd_f32(const float* gx, const float* gh, const float* c_prev, const float* c_out,
+                                const float* dh, const float* dc_out, int B, int F, int HW, float* dg,
+                                float* dc_prev, kccot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * EXTENSION, no reference behaviour (BASELINE.json north_star names a "batch-vs-batch Gaussian

@@ -76,6 +76,46 @@ class ChannelLayerNorm(nn.Module):
         return self.ln(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
 
 
+class _ConvLSTMCellHIP(torch.autograd.Function):
+    """c, h = cell(gx_t, gh, c_prev): the gate arithmetic of one ConvLSTM step as ONE HIP launch each way
+    (kccot_convlstm_cell_{fwd,bwd}_f32) instead of a dozen elementwise kernels forward and twice that backward."""
+
+    @staticmethod
+    def forward(ctx, gx, gh, c_prev):
+        from ._lib import lib, ptr, check, stream_of, empty_like
+        gx, gh, c_prev = gx.contiguous(), gh.contiguous(), c_prev.contiguous()
+        B, F4 = gx.shape[0], gx.shape[1]
+        Fn, HW = F4 // 4, gx.shape[2] * gx.shape[3]
+        c, h = empty_like(c_prev), empty_like(c_prev)
+        check(lib.kccot_convlstm_cell_fwd_f32(ptr(gx), ptr(gh), ptr(c_prev), B, Fn, HW, ptr(c), ptr(h), stream_of(gx)), "convlstm_cell_fwd")
+        ctx.save_for_backward(gx, gh, c_prev, c)
+        return c, h
+
+    @staticmethod
+    def backward(ctx, dc, dh):
+        from ._lib import lib, ptr, check, stream_of, empty_like
+        gx, gh, c_prev, c = ctx.saved_tensors
+        B, F4 = gx.shape[0], gx.shape[1]
+        Fn, HW = F4 // 4, gx.shape[2] * gx.shape[3]
+        dc = dc.contiguous() if dc is not None else None
+        dh = dh.contiguous() if dh is not None else None
+        dg, dcp = empty_like(gx), empty_like(c_prev)
+        check(lib.kccot_convlstm_cell_bwd_f32(ptr(gx), ptr(gh), ptr(c_prev), ptr(c), ptr(dh) if dh is not None else None,
+                                              ptr(dc) if dc is not None else None, B, Fn, HW, ptr(dg), ptr(dcp), stream_of(gx)),
+              "convlstm_cell_bwd")
+        return dg, dg, dcp
+
+
+def _cell_torch(g, c):
+    gi, gf, gc, go = torch.chunk(g, 4, dim=1)
+    c = hard_sigmoid(gf) * c + hard_sigmoid(gi) * torch.tanh(gc)
+    return c, hard_sigmoid(go) * torch.tanh(c)
+
+
+# KCCOT_CONVLSTM_CELL=torch: the stock tensor-op cell (also what CPU tensors and double precision take)
+_CELL_HIP = os.environ.get("KCCOT_CONVLSTM_CELL", "hip") != "torch"
+
+
 class ConvLSTM2D(nn.Module):
     """Keras ConvLSTM2D(filters, kernel, strides, padding='same', return_sequences=True):
     the input convolution is strided, the recurrent one runs on the hidden state at stride 1;
@@ -95,18 +135,23 @@ class ConvLSTM2D(nn.Module):
 
     def forward(self, x):                             # [B, T, C, H, W] -> [B, T, F, H', W']
         B, T = x.shape[:2]
+        # all frames in one conv, TIME-MAJOR: the per-step slices below are then whole contiguous tensors taken with
+        # unbind (its backward is ONE stack) -- slicing a batch-major [B, T, ...] result per step costs a zero-filled
+        # full-size gradient tensor and an add per step in the backward (7 % + 2 % of the training iteration's GPU time)
+        xt = x.transpose(0, 1).reshape((T * B,) + x.shape[2:])
         with _backend("convlstm"):
-            gx = self.wx(F.pad(x.reshape((B * T,) + x.shape[2:]), self.pad_x))   # all frames in one conv
-        gx = gx.reshape(B, T, 4 * self.filters, *self.out_hw)
+            gx = self.wx(F.pad(xt, self.pad_x))
+        gxs = gx.reshape(T, B, 4 * self.filters, *self.out_hw).unbind(0)
         h = x.new_zeros(B, self.filters, *self.out_hw)
         c = torch.zeros_like(h)
         outs = []
         for t in range(T):
             with _backend("convlstm"):
-                g = gx[:, t] + self.wh(F.pad(h, self.pad_h))
-            gi, gf, gc, go = torch.chunk(g, 4, dim=1)
-            c = hard_sigmoid(gf) * c + hard_sigmoid(gi) * torch.tanh(gc)
-            h = hard_sigmoid(go) * torch.tanh(c)
+                gh = self.wh(F.pad(h, self.pad_h))
+            if _CELL_HIP and gh.is_cuda and gh.dtype == torch.float32:
+                c, h = _ConvLSTMCellHIP.apply(gxs[t], gh, c)
+            else:
+                c, h = _cell_torch(gxs[t] + gh, c)
             outs.append(h)
         return torch.stack(outs, dim=1)
 

@@ -78,3 +78,50 @@ def test_default_convolution_mode_in_a_child_process():
                        text=True, timeout=900)
     assert p.returncode == 0, "child exit code %d\n%s\n%s" % (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
     assert "done 6 False" in p.stdout, p.stdout[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 8, 5, 7), (2, 16, 8, 8), (4, 32, 4, 4), (1, 5, 3, 3)])
+def test_fused_convlstm_cell_equals_the_tensor_op_cell(shape):
+    """kccot_convlstm_cell_{fwd,bwd}_f32 (one launch per step and direction) against the stock tensor-op cell of
+    kccotgan_amd.gan (Keras ConvLSTM2D gate order i, f, c, o; hard_sigmoid recurrent activation): c, h and the gradients
+    w.r.t. both convolution outputs and the previous cell state, including pre-activations beyond the hard_sigmoid's
+    linear range, odd sizes (scalar kernel) and a missing upstream dc (NULL)."""
+    import torch
+    from kccotgan_amd import gan
+    B, Fn, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    gx = (4.0 * torch.randn(B, 4 * Fn, H, W, device="cuda", generator=g)).requires_grad_(True)
+    gh = (2.0 * torch.randn(B, 4 * Fn, H, W, device="cuda", generator=g)).requires_grad_(True)
+    c0 = torch.randn(B, Fn, H, W, device="cuda", generator=g).requires_grad_(True)
+    wc, wh = torch.randn(B, Fn, H, W, device="cuda", generator=g), torch.randn(B, Fn, H, W, device="cuda", generator=g)
+    c1, h1 = gan._ConvLSTMCellHIP.apply(gx, gh, c0)
+    c2, h2 = gan._cell_torch(gx + gh, c0)
+    assert torch.allclose(c1, c2, rtol=0, atol=2e-6) and torch.allclose(h1, h2, rtol=0, atol=2e-6)
+    for outs in (lambda c, h: (c * wc).sum() + (h * wh).sum(), lambda c, h: (h * wh).sum()):
+        ga = torch.autograd.grad(outs(c1, h1), (gx, gh, c0), retain_graph=True)
+        gb = torch.autograd.grad(outs(c2, h2), (gx, gh, c0), retain_graph=True)
+        for a, b in zip(ga, gb):
+            assert torch.allclose(a, b, rtol=0, atol=3e-6 * max(1.0, float(b.abs().max()))), float((a - b).abs().max())
+        assert torch.equal(ga[0], ga[1])
+
+
+@pytest.mark.gpu
+def test_convlstm_layer_with_the_fused_cell_equals_the_tensor_op_layer(monkeypatch):
+    """ConvLSTM2D end to end (strided input convolution for all frames, recurrent convolution per step, fused cell) against
+    the same module on the tensor-op cell: outputs and parameter / input gradients."""
+    import torch
+    from kccotgan_amd import gan
+    torch.manual_seed(3)
+    layer = gan.ConvLSTM2D(3, 8, 5, 2, (16, 16), bias=True).cuda()
+    x = torch.randn(2, 6, 3, 16, 16, device="cuda", requires_grad=True)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(gan, "_CELL_HIP", mode)
+        with gan.conv_guard():
+            y = layer(x)
+            gr = torch.autograd.grad((y * y).sum(), [x] + list(layer.parameters()))
+        res[mode] = (y.detach(), gr)
+    assert torch.allclose(res[True][0], res[False][0], rtol=0, atol=1e-5)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.allclose(a, b, rtol=0, atol=2e-5 * max(1.0, float(b.abs().max())))

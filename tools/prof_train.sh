@@ -1,6 +1,6 @@
 #!/bin/bash
-# per-kernel durations of the full training iteration (fast-find MIOpen): rocprofv3 --kernel-trace --stats
-export TMPDIR=/tmp MIOPEN_FIND_MODE=2
+# per-kernel durations of the full training iteration (default find mode + shipped find-db; FAST_FIND=1: MIOPEN_FIND_MODE=2): rocprofv3 --kernel-trace --stats
+export TMPDIR=/tmp; [ -n "$FAST_FIND" ] && export MIOPEN_FIND_MODE=2
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python3 tools/bench_train.py --json --iters 2 --kernel 3d > gpurun_out/prof_train.log 2>&1 || { tail -5 gpurun_out/prof_train.log; exit 1; }
 grep "^{" gpurun_out/prof_train.log
 f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1)
