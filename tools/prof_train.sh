@@ -3,7 +3,7 @@
 export TMPDIR=/tmp; [ -n "$FAST_FIND" ] && export MIOPEN_FIND_MODE=2
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python3 tools/bench_train.py --json --iters 2 --kernel 3d > gpurun_out/prof_train.log 2>&1 || { tail -5 gpurun_out/prof_train.log; exit 1; }
 grep "^{" gpurun_out/prof_train.log
-f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1)
+f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1); find gpurun_out/prof_train -name "*kernel_trace.csv" -delete
 python3 - $f <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
