@@ -265,6 +265,23 @@ int kccot_convlstm_cell_bwd_f32(const float* gx, const float* gh, const float* c
                                 float* dc_prev, kccot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * LayerNormalization over the CHANNELS of an NCHW tensor (the
+ * tf.keras.layers.LayerNormalization(axis=-1) behind every ConvLSTM2D / Conv2DTranspose of the
+ * generator, gan.py:60-85,216-266, applied there to channels-last data): for every (n, pixel)
+ *   y[n,c,p] = (x[n,c,p] - mean) * rstd * gamma[c] + beta[c],   mean / biased variance over c,
+ *   rstd = 1 / sqrt(var + eps)
+ * on the NCHW layout the convolutions produce (no permute, no copy).  x, y: [N,C,HW]; gamma, beta: [C];
+ * mean, rstd: [N,HW] (saved for the backward).  Backward: dx [N,C,HW]; the parameter gradients come as
+ * per-chunk partial sums partials[chunk][2][C] (dgamma, dbeta) that the caller adds up in chunk order
+ * (deterministic); kccot_channel_layernorm_chunks(N, C, HW) = number of chunks. */
+int kccot_channel_layernorm_chunks(int N, int C, int HW);
+int kccot_channel_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, int N, int C, int HW,
+                                    float eps, float* y, float* mean, float* rstd, kccot_stream_t stream);
+int kccot_channel_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                    const float* rstd, int N, int C, int HW, float* dx, float* partials,
+                                    kccot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * EXTENSION, no reference behaviour (BASELINE.json north_star names a "batch-vs-batch Gaussian
  * kernel / MMD matrix"; the reference only imports sklearn's rbf_kernel, data_utils.py:16, and never
  * calls it).  Defined with sklearn.metrics.pairwise.rbf_kernel semantics: K = exp(-gamma * D) on

@@ -72,6 +72,9 @@ SIGNATURES = {
     "kccot_rbf_mmd_bwd_f32": (_i, [_fp, _i, _f, _fp, _fp, _fp]),
     "kccot_smooth_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "kccot_smooth_fwd_f32": (_i, [_fp, _i, _i, _i, _i, _i, _f, _i, _u, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_channel_layernorm_chunks": (_i, [_i, _i, _i]),
+    "kccot_channel_layernorm_fwd_f32": (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _fp, _fp, _fp, _fp]),
+    "kccot_channel_layernorm_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp]),
     "kccot_convlstm_cell_fwd_f32": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp]),
     "kccot_convlstm_cell_bwd_f32": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp]),
     "kccot_smooth_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _i, _u, _fp, _fp, _sz, _fp]),

@@ -65,14 +65,49 @@ def hard_sigmoid(x):
     return torch.clamp(0.2 * x + 0.5, 0.0, 1.0)
 
 
+class _ChannelLayerNormHIP(torch.autograd.Function):
+    """LayerNorm over the channels of an NCHW tensor on its native layout (kccot_channel_layernorm_{fwd,bwd}_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        from ._lib import lib, ptr, check, stream_of, empty_like, empty
+        x = x.contiguous()
+        N, C, HW = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+        y = empty_like(x)
+        mean, rstd = empty((N, HW), torch.float32, x.device), empty((N, HW), torch.float32, x.device)
+        check(lib.kccot_channel_layernorm_fwd_f32(ptr(x), ptr(gamma), ptr(beta), N, C, HW, eps, ptr(y), ptr(mean), ptr(rstd),
+                                                  stream_of(x)), "channel_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ._lib import lib, ptr, check, stream_of, empty_like, empty
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, C, HW = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+        dx = empty_like(x)
+        parts = empty((int(lib.kccot_channel_layernorm_chunks(N, C, HW)), 2, C), torch.float32, x.device)
+        check(lib.kccot_channel_layernorm_bwd_f32(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), N, C, HW, ptr(dx), ptr(parts),
+                                                  stream_of(x)), "channel_layernorm_bwd")
+        sums = parts.sum(0)
+        return dx, sums[0], sums[1], None
+
+
+# KCCOT_CHANNEL_LN=torch: nn.LayerNorm on the permuted tensor (also what CPU tensors take)
+_LN_HIP = os.environ.get("KCCOT_CHANNEL_LN", "hip") != "torch"
+
+
 class ChannelLayerNorm(nn.Module):
     """tf.keras.layers.LayerNormalization(axis=[-1]) on a channels-last tensor, applied to NCHW data."""
 
     def __init__(self, channels):
         super().__init__()
-        self.ln = nn.LayerNorm(channels, eps=1e-3)   # Keras epsilon default
+        self.ln = nn.LayerNorm(channels, eps=1e-3)   # Keras epsilon default; holds gamma / beta
 
     def forward(self, x):                             # [N, C, H, W]
+        if _LN_HIP and x.is_cuda and x.dtype == torch.float32:
+            return _ChannelLayerNormHIP.apply(x, self.ln.weight, self.ln.bias, self.ln.eps)
         return self.ln(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
 
 

@@ -125,3 +125,28 @@ def test_convlstm_layer_with_the_fused_cell_equals_the_tensor_op_layer(monkeypat
     assert torch.allclose(res[True][0], res[False][0], rtol=0, atol=1e-5)
     for a, b in zip(res[True][1], res[False][1]):
         assert torch.allclose(a, b, rtol=0, atol=2e-5 * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(6, 32, 8, 8), (3, 64, 5, 7), (40, 16, 4, 4), (2, 256, 4, 4), (1, 3, 33, 17)])
+def test_channel_layernorm_kernels_equal_the_permuted_nn_layernorm(shape, monkeypatch):
+    """kccot_channel_layernorm_{fwd,bwd}_f32 (LayerNorm over the channels of an NCHW tensor on its native layout) against
+    nn.LayerNorm on the permuted tensor (the Keras LayerNormalization(axis=-1) of the reference's generator, eps 1e-3):
+    outputs, input gradient and the gamma / beta gradients (per-chunk partial sums added in order)."""
+    import torch
+    from kccotgan_amd import gan
+    torch.manual_seed(sum(shape))
+    ln = gan.ChannelLayerNorm(shape[1]).cuda()
+    with torch.no_grad():
+        ln.ln.weight.copy_(torch.randn(shape[1]).abs() + 0.5)
+        ln.ln.bias.copy_(torch.randn(shape[1]))
+    x = (2.0 * torch.randn(shape, device="cuda") + 0.7).requires_grad_(True)
+    w = torch.randn(shape, device="cuda")
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(gan, "_LN_HIP", mode)
+        y = ln(x)
+        res[mode] = (y.detach(), torch.autograd.grad((y * w).sum(), [x, ln.ln.weight, ln.ln.bias]))
+    assert torch.allclose(res[True][0], res[False][0], rtol=0, atol=5e-6 * float(res[False][0].abs().max()))
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.allclose(a, b, rtol=0, atol=2e-5 * max(1.0, float(b.abs().max()))), float((a - b).abs().max())
