@@ -38,6 +38,7 @@ struct TileArgs {
     int64_t K, chunk;
     float* part;      // [npairs][nchunk][TELEMS]
     const unsigned short* planes;   // PLANES build: pre-split stack [3][2B][K] bf16 (presplit_stack), else null
+    const float* ediff;             // E = fake - real [B][K] formed ONCE (ediff_rows), or null: E panels subtract while staging
 };
 
 // ---- one-time exact three-way split of the stack [real ; fake - real] into bf16 planes (round 2) ---------------------
@@ -83,6 +84,19 @@ __global__ __launch_bounds__(256) void presplit_stack(const float* __restrict__ 
     *reinterpret_cast<uint4*>(planes + o) = ph;
     *reinterpret_cast<uint4*>(planes + plane + o) = pm;
     *reinterpret_cast<uint4*>(planes + 2 * plane + o) = pl;
+}
+
+// E = fake - real once, in fp32 (the same subtraction the producers do while staging: bit-identical sums).  Why it pays
+// for large batches: the tile kernel is bound by the bytes its workgroups pull through L2 (PMC: 3.3x the algorithmic
+// bytes at B = 256, 9.5x at B = 512 -- pairs that share a panel drift apart and re-fetch it), and a panel of E costs TWO
+// row streams (fake and real) every time it is staged: 96 panel streams per K-range at B = 512 against 64 with E
+// materialised (-33 % of the streams; measured -19 % of the kernel), for one extra streaming pass (read 2, write 1 tensors).
+__global__ __launch_bounds__(256) void ediff_rows(const float* __restrict__ real, const float* __restrict__ fake, int64_t n4,
+                                                  float* __restrict__ e) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(fake)[i], b = reinterpret_cast<const float4*>(real)[i];
+        reinterpret_cast<float4*>(e)[i] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    }
 }
 
 __device__ __forceinline__ float4 tld4(const float* __restrict__ row, int64_t k, int64_t kend) {
@@ -139,6 +153,7 @@ __device__ __forceinline__ void tile_pair(int q, int nt, int& pa, int& pb) {
 __device__ __forceinline__ void panel_rows(const TileArgs& a, int p, const float*& main, const float*& sub) {
     const int r0 = p * TP;
     if (r0 < a.B) { main = a.real + (int64_t)r0 * a.K; sub = nullptr; }
+    else if (a.ediff) { main = a.ediff + (int64_t)(r0 - a.B) * a.K; sub = nullptr; }
     else { main = a.fake + (int64_t)(r0 - a.B) * a.K; sub = a.real + (int64_t)(r0 - a.B) * a.K; }
 }
 
@@ -458,7 +473,16 @@ __global__ __launch_bounds__(256) void gram_tile_finalize(TileFin f) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-struct TilePlan { int nt, npairs, nchunk; int64_t chunk; size_t part_bytes, gsum_bytes, planes_bytes, ws_bytes; };
+struct TilePlan { int nt, npairs, nchunk; int64_t chunk; size_t part_bytes, gsum_bytes, planes_bytes, ediff_bytes, ws_bytes; };
+
+// E = fake - real materialised once for B >= 512 (KCCOT_GRAM_EDIFF_MINB overrides; 0 = never).  Measured cost stage, the
+// extra pass included (tools/ab_ediff.sh, profiles/r03ac_ab_ediff.txt): B = 512 (K = 2.36 M) 22.6 -> 21.1-21.3 ms (the tile
+// kernel alone 22.6 -> ~18.3 ms) for 4.8 GB more workspace; B = 384 equal (2.14 vs 2.13 ms); B = 256 SLOWER (1.12 vs 1.04 ms)
+static bool tiled_ediff(int B) {
+    int minb = 512;
+    if (const char* e = getenv("KCCOT_GRAM_EDIFF_MINB")) minb = atoi(e);
+    return minb > 0 && B >= minb;
+}
 
 // Pre-split planes are OPT-IN (KCCOT_GRAM_PRESPLIT=1): measured slower than the in-kernel split (B = 256: 1.38 vs 1.22 ms
 // for the cost stage, B = 512: 31.2 vs 26.7 ms).  The diagnostic builds showed why: with the planes the kernel itself
@@ -494,7 +518,8 @@ static TilePlan plan_tiled(int B, int64_t K) {
     pl.part_bytes = align_up((size_t)pl.npairs * pl.nchunk * TELEMS * sizeof(float), 256);
     pl.gsum_bytes = align_up((size_t)pl.npairs * TELEMS * sizeof(double), 256);
     pl.planes_bytes = tiled_presplit(B, K) ? align_up((size_t)3 * 2 * B * K * sizeof(unsigned short), 256) : 0;
-    pl.ws_bytes = pl.part_bytes + pl.gsum_bytes + pl.planes_bytes;
+    pl.ediff_bytes = (!pl.planes_bytes && tiled_ediff(B)) ? align_up((size_t)B * K * sizeof(float), 256) : 0;
+    pl.ws_bytes = pl.part_bytes + pl.gsum_bytes + pl.planes_bytes + pl.ediff_bytes;
     return pl;
 }
 
@@ -530,7 +555,13 @@ int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void*
     double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.part_bytes);
     int rc;
     if (stage != 2) {
-        TileArgs ta{cb.p[0].x, cb.p[0].y, B, pl.nt, pl.nchunk, K, pl.chunk, part, nullptr};
+        TileArgs ta{cb.p[0].x, cb.p[0].y, B, pl.nt, pl.nchunk, K, pl.chunk, part, nullptr, nullptr};
+        if (pl.ediff_bytes) {
+            float* e = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.part_bytes + pl.gsum_bytes);
+            hipLaunchKernelGGL(ediff_rows, dim3(2048), dim3(256), 0, st, cb.p[0].x, cb.p[0].y, (int64_t)B * K / 4, e);
+            if ((rc = launch_status("ediff_rows"))) return rc;
+            ta.ediff = e;
+        }
         if (pl.planes_bytes && tiled_presplit(B, K)) {
             unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + pl.part_bytes + pl.gsum_bytes);
             const int64_t ngroups = (int64_t)2 * B * (K >> 3);

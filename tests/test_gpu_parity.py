@@ -477,6 +477,24 @@ def test_tiled_gram_presplit_planes_equal_the_in_kernel_split(G, B, monkeypatch)
     np.testing.assert_allclose(out["planes"][0], ref, rtol=0, atol=1e-5 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("B", [128, 256, 384])
+def test_tiled_gram_with_materialised_difference_rows_equals_subtracting_while_staging(G, B, monkeypatch):
+    """Large batches (default B >= 512; KCCOT_GRAM_EDIFF_MINB) form E = fake - real ONCE in fp32 (ediff_rows) and the tiled
+    Gram's E panels stream that buffer instead of subtracting two row streams every time a panel is staged.  Same
+    subtraction, same split, same MFMAs: the three cost matrices are bit-identical either way."""
+    rng = np.random.default_rng(3000 + B)
+    K, T, J = 2560 + 36, 10, 8
+    real = torch.from_numpy(rng.random((B, K), dtype=np.float32)).to(DEV)
+    fake = torch.from_numpy(np.clip(real.cpu().numpy() + 0.05 * rng.standard_normal((B, K)).astype(np.float32), 0, 1)).to(DEV)
+    f = [torch.from_numpy(rng.random((B, T, J), dtype=np.float32)).to(DEV) for _ in range(4)]
+    out = {}
+    for mode, minb in (("ediff", "128"), ("staging", "0")):
+        monkeypatch.setenv("KCCOT_GRAM_EDIFF_MINB", minb)
+        out[mode] = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
+    assert np.isfinite(out["ediff"]).all()
+    assert _same_bits(out["ediff"], out["staging"])
+
+
 @pytest.mark.parametrize("B,K", [(64, 122880), (64, 4100), (37, 3076), (7, 256), (64, 64 * 300 + 36), (33, 128)])
 def test_gram_two_stage_producers_equal_the_one_stage_form(G, B, K, monkeypatch):
     """The default producers of gram128_partial_x3ws keep two stages of UNCONDITIONAL (clamped) loads in flight and zero
