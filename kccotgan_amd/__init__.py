@@ -46,7 +46,9 @@ def _install_miopen_find_db(force=False):
         _os.makedirs(dst, exist_ok=True)
         for f in files:
             if not _os.path.exists(_os.path.join(dst, f)):
-                shutil.copyfile(_os.path.join(src, f), _os.path.join(dst, f))
+                tmp = _os.path.join(dst, ".%s.%d.tmp" % (f, _os.getpid()))     # one process per GPU imports this at once:
+                shutil.copyfile(_os.path.join(src, f), tmp)                     # never let a rank see a half-written file
+                _os.replace(tmp, _os.path.join(dst, f))
         _os.environ["MIOPEN_USER_DB_PATH"] = dst
         return dst
     except OSError:
