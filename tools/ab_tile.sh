@@ -1,3 +1,6 @@
+#!/bin/bash
+# A/B of the tiled Gram between libkccot_old.so (tools/build_old_lib.sh <commit>) and the working tree: parity tests, then the
+# cost stage at B = 128 / 256 / 512, alternating, two rounds.
 set -o pipefail
 # needs kccotgan_amd/csrc/libkccot_old.so: tools/build_old_lib.sh <commit> (run here, the .so travels with the snapshot)
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "tiled or gram or full_size or large_batch or cost" > gpurun_out/r02y_tests.log 2>&1; tail -3 gpurun_out/r02y_tests.log
