@@ -149,7 +149,9 @@ def test_hip_smoothing_random_shapes_against_the_pinned_oracle():
     from oracle import smoothing_torch as st
     rng = np.random.default_rng(77)
     shapes = [(1, 5, 4, 6, 1), (2, 7, 5, 9, 2), (3, 9, 11, 5, 3), (1, 6, 6, 7, 4), (2, 70, 8, 6, 1), (2, 8, 66, 8, 1),
-              (1, 12, 7, 130, 1), (2, 16, 9, 16, 3), (4, 8, 8, 8, 1), (1, 33, 5, 17, 2)]
+              (1, 12, 7, 130, 1), (2, 16, 9, 16, 3), (4, 8, 8, 8, 1), (1, 33, 5, 17, 2),
+              # round 2: shapes that only the any-length / any-channel kernels take
+              (2, 10, 9, 7, 3), (1, 8, 70, 5, 2), (2, 130, 6, 6, 1), (1, 9, 9, 300, 1), (1, 5, 5, 5, 7), (3, 6, 48, 12, 3)]
     for shape in shapes:
         for ksize, sigma in ((6, 5.0), (8, 1.3)):
             r = ksize // 2
