@@ -15,6 +15,7 @@
 //                         of at most 64 rows (the BASELINE configs[1] shape).
 #include "common.h"
 #include "cost_internal.h"
+#include "options.h"
 
 namespace kccot {
 
@@ -325,6 +326,8 @@ static int run_cost(CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J
     if (stage && (partial_only || (flags & KCCOT_COST_FORCE_DIRECT) || !loss3))
         return fail(KCCOT_EINVAL, "pairwise_cost: the Gram-sum split applies to kccot_pairwise_cost3_f32 on the Gram paths only");
     if (mfma) return run_gram(cb, loss3, K, sc, T, J, ws, ws_bytes, partial_only, st, stage);
+    if (!(flags & KCCOT_COST_FORCE_DIRECT) && !partial_only && gram_q256_eligible(cb, K, loss3))
+        return run_gram_q256(cb, K, sc, T, J, ws, ws_bytes, st, stage);
     if (!(flags & KCCOT_COST_FORCE_DIRECT) && !partial_only && gram_tiled_eligible(cb, K, loss3))
         return run_gram_tiled(cb, K, sc, T, J, ws, ws_bytes, st, stage);
     if (stage) return fail(KCCOT_EUNSUPPORTED, "pairwise_cost3: no Gram path for B=%d K=%lld (Gram-sum split)", cb.p[0].Bx, (long long)K);
@@ -370,7 +373,9 @@ extern "C" size_t kccot_pairwise_cost3_workspace_bytes(int B, int64_t K) {
     size_t a = plan_direct(3, Bs, Bs, same, K).ws_bytes;
     size_t b = plan_gram(K).ws_bytes;
     size_t c = gram_tiled_workspace_bytes(B, K);
+    size_t d = gram_q256_workspace_bytes(B, K);
     a = a > b ? a : b;
+    c = c > d ? c : d;
     return a > c ? a : c;
 }
 
@@ -378,10 +383,10 @@ extern "C" int kccot_pairwise_cost3_gram_sums_span(int B, int64_t K, size_t* byt
     if (!byte_offset || !n_doubles) return fail(KCCOT_EINVAL, "gram_sums_span: null pointer");
     *byte_offset = 0; *n_doubles = 0;
     if (B <= 0 || K <= 0 || K % 4 != 0 || K < 256) return 0;
-    const char* e = getenv("KCCOT_GRAM_F32");
-    const bool x3 = !(e && atoi(e) == 1);
+    const bool x3 = !opt(OPT_GRAM_F32);
     if (B <= 64) gram_sums_span(K, byte_offset, n_doubles);
-    else if (x3 && B % 128 == 0 && B <= 4096 && !getenv("KCCOT_COST_NO_TILED")) gram_tiled_sums_span(B, K, byte_offset, n_doubles);
+    else if (gram_q256_applies(B, K)) gram_q256_sums_span(B, K, byte_offset, n_doubles);
+    else if (x3 && B % 128 == 0 && B <= 4096 && opt(OPT_COST_TILED)) gram_tiled_sums_span(B, K, byte_offset, n_doubles);
     return 0;
 }
 

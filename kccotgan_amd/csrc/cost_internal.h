@@ -126,6 +126,13 @@ int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void*
                    int stage = 0);
 void gram_tiled_sums_span(int B, int64_t K, size_t* off, size_t* n);
 void gram_sums_span(int64_t K, size_t* off, size_t* n);
+// cost_tile256.hip: batches that are multiples of 256 -- the same Gram in 256 x 256 tiles, E written as a by-product
+bool gram_q256_applies(int B, int64_t K);
+bool gram_q256_eligible(const CostBatch& cb, int64_t K, bool loss3);
+size_t gram_q256_workspace_bytes(int B, int64_t K);
+int run_gram_q256(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st,
+                  int stage = 0);
+void gram_q256_sums_span(int B, int64_t K, size_t* off, size_t* n);
 bool gram_blocked_eligible(const CostBatch& cb, int64_t K, bool loss3);
 int run_gram_blocked(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st);
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-only timing of the cost-assembly stage (kccot_pairwise_cost3_f32) at a large batch.
-usage: bench_gram.py [B H T W C]; env: KCCOT_GRAM_NO_PRESPLIT, KCCOT_GRAM_PRESPLIT"""
+usage: bench_gram.py [B H T W C]; options through KCCOT_OPTIONS (e.g. cost_tiled=0)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,7 +22,6 @@ e0.record()
 for _ in range(reps): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-npairs = (2 * B // 128) * (2 * B // 128 + 1) // 2
-fl = npairs * 128 * 128 * K * 2.0 * 6
-print("B=%d K=%d: cost stage %.3f ms  (%.2f PFLOP/s bf16 executed, workspace %.2f GB)  NO_PRESPLIT=%s" % (
-    B, K, ms, fl / ms / 1e12, wsb / 1e9, os.environ.get("KCCOT_GRAM_NO_PRESPLIT", "0")))
+fl = 2.0 * B * B * K * 2.0 * 6          # useful: X X^T and E E^T upper triangles + X E^T, six bf16 products per fp32 product
+print("B=%d K=%d: cost stage %.3f ms  (%.2f PFLOP/s bf16 useful, workspace %.2f GB)  KCCOT_OPTIONS=%s" % (
+    B, K, ms, fl / ms / 1e12, wsb / 1e9, os.environ.get("KCCOT_OPTIONS", "")))
