@@ -28,7 +28,6 @@
 #include "common.h"
 #include "cost_internal.h"
 #include "options.h"
-#include <type_traits>
 
 namespace kccot {
 
@@ -82,13 +81,17 @@ __device__ __forceinline__ void q256_mfma6(qf32x16& acc, const QFrag& a, const Q
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
 }
 
-// SAME (a diagonal pair, pa == pb: only panel A is staged) is a template parameter so that the staging code of each form is
-// straight-line and the compiler interleaves ALL of it with the MFMAs of the step.
-template <bool EPAIR, bool SAME>
+// SAME (a diagonal pair, pa == pb: only panel A is staged) and RAGGED (K % 32 != 0: the last granule of the last chunk is
+// partial, values past K are zeroed) are template parameters so that the staging code of each form is straight-line and the
+// compiler interleaves ALL of it with the MFMAs of the step.
+template <bool EPAIR, bool SAME, bool RAGGED>
 __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int chunk_id, unsigned char* zs0, unsigned char* zs1) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr int NP = SAME ? 8 : 16;
+    // granules in flight: a diagonal pair stages half as much and has the registers for two (its steps are short: 60
+    // MFMAs against 96, so one step of load latency cover is not enough)
+    constexpr int DEPTH = SAME ? 2 : 1;
     const int64_t K = a.K;
     const int64_t kbeg = (int64_t)chunk_id * a.chunk;
     const int64_t kend = (kbeg + a.chunk < K) ? kbeg + a.chunk : K;
@@ -116,11 +119,13 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
     const int64_t kmax = K - 4;                                              // K % 4 == 0, K >= 256 (host checks)
     const int woff = rr * QROWB + 4 * q;                                     // + 32 p rows
 
-    float4 G[NP];
+    // The loads are UNCONDITIONAL (column clamped into the row): granules past the end of the chunk are fetched, split and
+    // staged like any other -- into an LDS stage no step reads -- so the granule loop has one straight-line body.
+    float4 G0[NP], G1[DEPTH == 2 ? NP : 1];
     float2 carry[NP];
-    auto issue = [&](int g) {
+    auto issue = [&](float4 (&G)[NP], int g) {
         int64_t k = kbeg + (int64_t)g * QG + 4 * q;
-        k = k < kmax ? k : kmax;                                             // clamped: the loads are unconditional
+        k = k < kmax ? k : kmax;
         const unsigned vo = lrow + (unsigned)(k * 4);
 #pragma unroll
         for (int p = 0; p < 8; ++p)
@@ -132,20 +137,20 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
         }
     };
     // granule g has landed: E rows formed (EPAIR), the even step's pairs split into `zs`, the odd step's kept in `carry`
-    // (MASK: the granule may be the ragged last one of the chunk -- only then are values past kend zeroed)
-    auto emit_even = [&](int g, unsigned char* zs, auto mask) {
-        constexpr bool MASK = decltype(mask)::value;
+    auto emit_even = [&](float4 (&G)[NP], int g, unsigned char* zs) {
         const int64_t k = kbeg + (int64_t)g * QG + 4 * q;
-        const bool kok = !MASK || k + 4 <= kend;                             // false only in a ragged last granule
+        const bool kok = k + 4 <= kend;                                      // false past the end of the chunk
+        const unsigned vo = lrow + (unsigned)((k < kmax ? k : kmax) * 4);    // where issue() read these columns
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             float4 v = G[p];
             if (EPAIR && p >= 8) {
                 v.x -= G[p - 8].x; v.y -= G[p - 8].y; v.z -= G[p - 8].z; v.w -= G[p - 8].w;
-                if (kok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(qu32x4, v), re, (int)(lrow + (unsigned)(k * 4)),
-                                                                (int)((p - 8) * rstep), 0);
+                // unconditional: a granule past the end of the chunk re-writes the E values of columns another workgroup
+                // owns -- the same bits from the same inputs -- rather than put a branch into the step's block
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(qu32x4, v), re, (int)vo, (int)((p - 8) * rstep), 0);
             }
-            if (MASK) { v.x = kok ? v.x : 0.f; v.y = kok ? v.y : 0.f; v.z = kok ? v.z : 0.f; v.w = kok ? v.w : 0.f; }
+            if (RAGGED) { v.x = kok ? v.x : 0.f; v.y = kok ? v.y : 0.f; v.z = kok ? v.z : 0.f; v.w = kok ? v.w : 0.f; }
             q256_split_store(zs, woff + 32 * p * QROWB, v.x, v.y);
             carry[p] = make_float2(v.z, v.w);
         }
@@ -213,7 +218,7 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
     // at most one LDS read, three VALU instructions of the split, one LDS write and one buffer load.  One wave per SIMD:
     // whatever is not issued inside an MFMA's 24 free issue cycles is exposed, and hipcc's own order left runs of ten
     // VALU instructions between two MFMAs next to runs of nine bare MFMAs.
-    auto interleave = [&]() {
+    auto interleave = [&](bool with_loads) {
         __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
 #pragma unroll
         for (int m = 0; m < 6 * NT; ++m) {
@@ -221,45 +226,44 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            // the next granule's loads (and the E stores) spread over the whole step, one per 6 * NT / NP MFMAs: issued as a
+            // burst they back up the CU's memory pipeline, and a wave stuck in a VMEM issue issues no MFMA either (one wave
+            // per SIMD; measured: without the loads the same kernel keeps the matrix pipe 82 % busy instead of 59 %)
+            if (with_loads && (m % (6 * NT / NP)) == (6 * NT / NP) - 1) __builtin_amdgcn_sched_group_barrier(0x030, EPAIR ? 2 : 1, 0);
         }
     };
-    // The granule loop is peeled so that every block of the steady state is straight-line code: a conditional around the
-    // staging of the next granule put the whole split behind the step's 96 MFMAs instead of in their shadow.
-    constexpr std::true_type masked{};
-    constexpr std::false_type plain{};
-    issue(0);
-    emit_even(0, zs0, masked);
-    if (ng > 1) issue(1);
-    lds_barrier();
-    int g = 0;
-    for (; g + 2 < ng; ++g) {                                                // granule g + 1 is not the last one, g + 2 exists
+    // One granule = two steps.  Its odd step splits the even half of the NEXT granule out of `G` (loads issued DEPTH granules
+    // earlier) and re-issues `G` for the granule DEPTH further on.
+    auto granule = [&](float4 (&G)[NP], int g) {
         step(zs0);
         emit_odd(zs1);
-        interleave();
+        interleave(false);
         __builtin_amdgcn_sched_barrier(0);                                   // (register-only MFMAs would drift across the asm barrier)
         lds_barrier();
         __builtin_amdgcn_sched_barrier(0);
         step(zs1);
-        emit_even(g + 1, zs0, plain);
-        issue(g + 2);
-        interleave();
+        emit_even(G, g + 1, zs0);
+        issue(G, g + 1 + DEPTH);
+        interleave(true);
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
         __builtin_amdgcn_sched_barrier(0);
-    }
-    if (g + 1 < ng) {                                                        // g = ng - 2: stages the last granule
-        step(zs0);
-        emit_odd(zs1);
-        lds_barrier();
-        step(zs1);
-        emit_even(g + 1, zs0, masked);
-        lds_barrier();
-    }
-    step(zs0);                                                               // the last granule
-    emit_odd(zs1);
+    };
+    issue(G0, 0);
+    if constexpr (DEPTH == 2) issue(G1, 1);
+    emit_even(G0, 0, zs0);
+    issue(G0, DEPTH);
     lds_barrier();
-    step(zs1);
+    if constexpr (DEPTH == 2) {
+        int g = 0;
+        for (; g + 1 < ng; g += 2) {
+            granule(G1, g);
+            granule(G0, g + 1);
+        }
+        if (g < ng) granule(G1, g);
+    } else {
+        for (int g = 0; g < ng; ++g) granule(G0, g);
+    }
 
     // accumulator register r of lane l is element ((r & 3) + 8 (r >> 2) + 4 (l >> 5), l & 31) of its 32 x 32 tile
     float* o = a.part + ((int64_t)q256_pair_slot(a.nt, pa, pb) * a.nchunk + chunk_id) * QELEMS + (4 * (lane >> 5)) * QP + (lane & 31);
@@ -283,7 +287,7 @@ __host__ __device__ inline int q256_mode_pairs(int mode, int nx) {
     return mode == Q256_EPAIR ? nx : (mode == Q256_DIAG ? nt : nt * (nt - 1) / 2 - nx);
 }
 
-template <int MODE>
+template <int MODE, bool RAGGED>
 __global__ __launch_bounds__(256) void gram_q256(Q256Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char zs0[QSLOT];
     __shared__ __attribute__((aligned(16))) unsigned char zs1[QSLOT];
@@ -311,8 +315,8 @@ __global__ __launch_bounds__(256) void gram_q256(Q256Args a) {
     }
     if ((int64_t)chunk_id * a.chunk >= a.K) return;                          // an empty trailing chunk
     // (the integer division above runs on the VALU: make the uniformity of what the buffer descriptors are built from explicit)
-    q256_body<MODE == Q256_EPAIR, MODE == Q256_DIAG>(a, __builtin_amdgcn_readfirstlane(pa), __builtin_amdgcn_readfirstlane(pb),
-                                                     __builtin_amdgcn_readfirstlane(chunk_id), zs0, zs1);
+    q256_body<MODE == Q256_EPAIR, MODE == Q256_DIAG, RAGGED>(a, __builtin_amdgcn_readfirstlane(pa), __builtin_amdgcn_readfirstlane(pb),
+                                                             __builtin_amdgcn_readfirstlane(chunk_id), zs0, zs1);
 }
 
 // fp64 sum over the chunks, fixed order; eight loads in flight
@@ -449,13 +453,22 @@ int run_gram_q256(const CostBatch& cb, int64_t K, float sc, int T, int J, void* 
     int rc;
     if (stage != 2) {
         Q256Args qa{cb.p[0].x, cb.p[0].y, e, B, pl.nx, pl.nt, pl.nchunk, K, pl.chunk, part};
-        hipLaunchKernelGGL((gram_q256<Q256_EPAIR>), dim3(q256_mode_pairs(Q256_EPAIR, pl.nx) * pl.nchunk), dim3(256), 0, st, qa);
-        if ((rc = launch_status("gram_q256<epair>"))) return rc;
-        hipLaunchKernelGGL((gram_q256<Q256_DIAG>), dim3(q256_mode_pairs(Q256_DIAG, pl.nx) * pl.nchunk), dim3(256), 0, st, qa);
-        if ((rc = launch_status("gram_q256<diag>"))) return rc;
-        if (q256_mode_pairs(Q256_OFF, pl.nx) > 0) {
-            hipLaunchKernelGGL((gram_q256<Q256_OFF>), dim3(q256_mode_pairs(Q256_OFF, pl.nx) * pl.nchunk), dim3(256), 0, st, qa);
-            if ((rc = launch_status("gram_q256<off>"))) return rc;
+        const bool ragged = K % QG != 0;
+        for (int mode = 0; mode < 3; ++mode) {
+            const int np = q256_mode_pairs(mode, pl.nx);
+            if (np == 0) continue;
+            const dim3 grid(np * pl.nchunk), block(256);
+            if (mode == Q256_EPAIR) {
+                if (ragged) hipLaunchKernelGGL((gram_q256<Q256_EPAIR, true>), grid, block, 0, st, qa);
+                else hipLaunchKernelGGL((gram_q256<Q256_EPAIR, false>), grid, block, 0, st, qa);
+            } else if (mode == Q256_DIAG) {
+                if (ragged) hipLaunchKernelGGL((gram_q256<Q256_DIAG, true>), grid, block, 0, st, qa);
+                else hipLaunchKernelGGL((gram_q256<Q256_DIAG, false>), grid, block, 0, st, qa);
+            } else {
+                if (ragged) hipLaunchKernelGGL((gram_q256<Q256_OFF, true>), grid, block, 0, st, qa);
+                else hipLaunchKernelGGL((gram_q256<Q256_OFF, false>), grid, block, 0, st, qa);
+            }
+            if ((rc = launch_status("gram_q256"))) return rc;
         }
         const int nvalid = (int)((K + pl.chunk - 1) / pl.chunk);
         hipLaunchKernelGGL(gram_q256_reduce, dim3(QELEMS / 256, pl.npairs), dim3(256), 0, st, (const float*)part, pl.nchunk, nvalid, pl.nt, gsum);
