@@ -45,6 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
+import kccotgan_amd  # noqa: E402,F401  (before the first CUDA call: its MIOpen solver switch must precede the GPU context)
 
 SHAPE = dict(B=64, H=64, T=30, W=64, C=1, J=8)
 SC = 1.0 / 15.0
@@ -130,8 +131,8 @@ def time_cost_kernel(t, reps=200):
 
 
 def time_sinkhorn(C3, L=100, reps=50):
-    """The three-problem solve and its reverse sweep alone (every iteration executed: KCCOT_SK_NO_SHORTCUT=1 is set
-    by main): us per launch and per dependent half-step."""
+    """The three-problem solve and its reverse sweep alone (every iteration executed: main sets the option
+    "sinkhorn_shortcut" = 0): us per launch and per dependent half-step."""
     from kccotgan_amd._lib import lib, ptr, stream_of, check
     n = C3.shape[1]
     dev = C3.device
@@ -211,7 +212,8 @@ def train_steps_child(timeout_s=150, fallback_timeout_s=240):
         return json.loads(out.strip().splitlines()[-1]), None
 
     t0 = time.perf_counter()
-    base = dict(os.environ, KCCOT_SK_NO_SHORTCUT="0")
+    base = dict(os.environ)
+    base.pop("KCCOT_OPTIONS", None)                 # the trainer child runs on the shipped defaults
     base.pop("MIOPEN_FIND_MODE", None)
     try:
         r, err = run(base, timeout_s)
@@ -373,7 +375,8 @@ def main():
     # 3 x 100 iterations (and the full reverse sweep) are executed whatever the data: `value` then
     # does not depend on how quickly the synthetic batch happens to reach its fp32 fixed point.  The
     # shipped default (shortcut on, bit-identical results) is timed separately below.
-    os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
+    from kccotgan_amd import _lib as kl
+    kl.set_option("sinkhorn_shortcut", 0)
     inp, t = make_inputs(SHAPE["B"], 0, dev)
     for k in WRT:
         t[k].requires_grad_(True)
@@ -479,7 +482,7 @@ def main():
       try:
         # the shipped default: exact shortcut on.  Same outputs bit for bit (tests/test_gpu_parity.py::
         # test_sinkhorn_periodic_state_shortcut_is_bit_exact); how much it saves depends on the data.
-        os.environ["KCCOT_SK_NO_SHORTCUT"] = "0"
+        kl.set_option("sinkhorn_shortcut", 1)
         from kccotgan_amd.graph import GraphedLossStep
 
         def timed(fn):
@@ -503,18 +506,18 @@ def main():
             extra[regime] = {"ms_per_step": ms_g, "ms_per_step_eager_launches": ms_e, "loss": float(l2),
                              "sinkhorn_iters": gs.nits.tolist(), "sinkhorn_iters_executed": gs.nits_executed.tolist()}
         out["with_exact_shortcut"] = extra
-        os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
+        kl.set_option("sinkhorn_shortcut", 0)
         out["eager_launches_ms_per_step"] = timed(lambda: loss_step(G, t))[0]     # shortcut off, like the headline
       except Exception as e:     # auxiliary measurements must not cost the headline line
         sys.stderr.write("bench: auxiliary timings failed: %r\n" % (e,))
-        os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
+        kl.set_option("sinkhorn_shortcut", 0)
     if rank == 0:       # the dominant kernel is the same on every rank at any N (replicated cost assembly at B <= 64)
       try:
         kt, K, C3 = time_cost_kernel(t)
         B, T, J = SHAPE["B"], SHAPE["T"], SHAPE["J"]
         alg_bytes = 2 * B * K * 4 + 16 * B * T * J + 12 * B * B            # read real+fake once
         alg_flops = 4 * B * B * K                                          # xy full + xx, yy triangles (8(d))
-        f32_path = os.environ.get("KCCOT_GRAM_F32") == "1"
+        f32_path = kl.get_option("gram_f32") == 1
         t_s = kt["partial"] * 1e-6
         traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -551,7 +554,7 @@ def main():
                     "f32_mfma_equivalent": {"achieved_tflops": tfl, "peak": MFMA_F32_PEAK_TFLOPS,
                                             "frac": tfl / MFMA_F32_PEAK_TFLOPS,
                                             "note": "algorithmic fp32 flops / time against the f32-input MFMA peak; "
-                                                    "applies to KCCOT_GRAM_F32=1, secondary here"}}
+                                                    "applies to the option gram_f32 = 1, secondary here"}}
         roof.update({"traffic": traffic, "traffic_source": traffic_source,
                      "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                      "kernel_us": kt["partial"], "cost_stage_us": kt["stage"],

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KCCOT_VERSION 201          /* 0.2.1 */
+#define KCCOT_VERSION 300          /* 0.3.0 */
 #define KCCOT_EINVAL (-1)          /* bad shape / null pointer / inconsistent arguments      */
 #define KCCOT_EUNSUPPORTED (-2)    /* valid request outside what this build implements       */
 #define KCCOT_EWORKSPACE (-3)      /* workspace too small                                    */
@@ -57,6 +57,40 @@ typedef void* kccot_stream_t;
 
 int kccot_version(void);
 const char* kccot_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Options.  Everything the library decides at run time beyond its arguments is in this table (the reference has no
+ * counterpart: it has one code path).  Process-wide, thread-safe (one atomic int each; a call in flight on another thread
+ * sees the old or the new value), read with plain loads on the call paths -- NO environment variable is consulted by any
+ * entry point.  kccot_set_option returns 0 or KCCOT_EINVAL (unknown name / value out of range).
+ * The environment variable KCCOT_OPTIONS="name=value,name=value" seeds the table ONCE, at the first use of the library
+ * (command-line tools: bench.py, tools/); a binding calls kccot_set_option.
+ *
+ *   name                      default  meaning
+ *   gram_f32                  0        1: cost matrices on the f32-input MFMA kernels (v_mfma_f32_32x32x2_f32) instead of the
+ *                                      exact bf16 three-way split -- same fp32 arithmetic, 1/16 of the matrix rate; parity runs
+ *   apply_f32                 0        1: the video gradient dfake = W [X;Y] on the f32-input MFMA kernel, likewise
+ *   cost_tiled                1        0: no tiled Gram kernels for B % 128 == 0 (the blocked or direct path serves instead)
+ *   cost_tile256              1        0: B % 256 == 0 runs the 128-row tiles of cost_tiled.hip instead of the 256-row ones
+ *   cost_blocked              1        0: no 64 x 64-block MFMA path for B % 64 == 0 (the direct VALU kernel serves instead)
+ *   apply_m256                1        0: the video gradient of B % 256 == 0 in 64-row blocks instead of 256-row tiles
+ *   sinkhorn_shortcut         1        0: execute every Sinkhorn iteration; 1: skip iterations EXACTLY once the fp32 state is
+ *                                      bit-for-bit periodic (identical results; see kccot_sinkhorn_fwd_f32)
+ *   sinkhorn_fused            1        0: kccot_sinkhorn_fused_eligible reports 0 (solve and reverse sweep as two launches)
+ *   sinkhorn_fused_max_n      64       largest n the fused solve + sweep launch accepts (<= 128; above 64 it spills registers)
+ *   sinkhorn_lanes_per_line   0        4 / 8 / 16 lanes per matrix line for 32 < n <= 64 (0: forward 8, reverse sweep 16)
+ *   sinkhorn_coop             1        0: 128 < n <= 1024 on the one-workgroup streaming solver instead of the multi-CU one
+ *   sinkhorn_coop_max_wg      0        > 0: workgroups the multi-CU solver may assume co-resident (a caller that runs in a
+ *                                      partition or under a CU mask); 0: queried from the device (CU count x occupancy, 3/4)
+ *   smooth_stream             1        0: KernelSmoothing on the per-axis global stencils (any radius) instead of the
+ *                                      streaming kernels (radius 3 / 4)
+ *   smooth_generic            0        1: the any-length / any-alignment streaming kernels even where the register-line ones apply
+ *   smooth_fused_tw           1        0: T and W stage of the 3-D smoothing as two launches instead of one
+ * ------------------------------------------------------------------------------------------- */
+int kccot_set_option(const char* name, int value);
+int kccot_get_option(const char* name, int* value);
+int kccot_option_count(void);
+const char* kccot_option_name(int index);      /* 0 <= index < kccot_option_count(), else NULL */
 
 /* ---------------------------------------------------------------------------------------------
  * Pairwise cost.  Replaces cost_xy (gan_utils.py:6-18), modified_cost (:21-43) and
@@ -141,7 +175,7 @@ int kccot_pairwise_cost_bwd_f32(const float* g, const float* x, const float* y, 
  * C is [nprob,n,n].  cost_out [nprob]; nits_out is device int32 [2*nprob]: nits_out[p] = the
  * iteration count of the reference's loop (what its `actual_nits` would be), nits_out[nprob+p] = the
  * iterations the kernel actually executed -- fewer when the fp32 state became bit-for-bit periodic
- * and the remaining iterations were skipped EXACTLY (KCCOT_SK_NO_SHORTCUT=1 disables that).
+ * and the remaining iterations were skipped EXACTLY (option "sinkhorn_shortcut" = 0 disables that).
  * u_hist / v_hist [nprob,L,n] receive u and v after every executed iteration (needed by the
  * backward; pass NULL for a forward-only evaluation).  pi_out [nprob,n,n] optional.
  * ------------------------------------------------------------------------------------------- */
@@ -208,10 +242,12 @@ int kccot_sinkhorn_loss_bwd_f32(const float* gloss, const float* real, const flo
 
 /* The same loss with the solves AND the reverse sweep in one persistent launch (the dual history stays in LDS; what
  * tf.GradientTape replays through the unrolled loop, kernel_train.py:287-289, is computed before the kernel leaves
- * the CU).  Eligible when n <= 128 and 2 (L+1) n floats of history fit the CU's LDS (kccot_sinkhorn_fused_eligible;
- * configs[0] and configs[1] are).  dC3_unit [3,n,n] = d loss / d C3 at dLoss = 1; the backward multiplies by the
- * upstream scalar `gloss` (one device float) while building its coefficients.  Costs, iteration counts and loss
- * are bit-identical to the two-launch form.  KCCOT_SK_NO_FUSED=1 reports "not eligible". */
+ * the CU).  Eligible -- ask kccot_sinkhorn_fused_eligible, do not size from a rule -- when n <= "sinkhorn_fused_max_n"
+ * (default 64: above that the kernel spills) and the dual history, 2 (L+1) NS floats with NS = n rounded up to the
+ * kernel's lane grid (entries per lane x lanes per line), fits 144 KB of LDS; configs[0] and configs[1] are.
+ * dC3_unit [3,n,n] = d loss / d C3 at dLoss = 1; the backward multiplies by the upstream scalar `gloss` (one device
+ * float) while building its coefficients.  Costs, iteration counts and loss are bit-identical to the two-launch form.
+ * Option "sinkhorn_fused" = 0 reports "not eligible". */
 int kccot_sinkhorn_fused_eligible(int n, int L);
 int kccot_sinkhorn_divergence_fused_f32(const float* C3, int n, float eps, int L, int Lmin, float thresh,
                                         float* cost3_out, int32_t* nits_out, float* loss_out, int32_t* ticket,

@@ -17,7 +17,15 @@ _user_value = _os.environ.get(MIOPEN_SWITCH)
 _gpu_was_live = "torch" in _sys.modules and _sys.modules["torch"].cuda.is_initialized()
 _os.environ.setdefault(MIOPEN_SWITCH, "0")
 MIOPEN_WORKAROUND_GUARANTEED = (_user_value == "0") or (_user_value is None and not _gpu_was_live)
-
+if not MIOPEN_WORKAROUND_GUARANTEED:
+    import warnings as _warnings
+    _warnings.warn(
+        "kccotgan_amd was imported after the GPU context was initialised (or %s is set to something other than 0): the "
+        "faulting MIOpen solver cannot be switched off reliably any more, so the G/D models (kccotgan_amd.gan) will run "
+        "their convolutions on the native ATen kernels -- about 7x slower per training iteration -- and the shipped MIOpen "
+        "find-db is not installed.  Import kccotgan_amd before the first CUDA call, or export %s=0 before starting Python.  "
+        "(The loss path -- gan_utils, data_utils -- is not affected.)" % (MIOPEN_SWITCH, MIOPEN_SWITCH),
+        RuntimeWarning, stacklevel=2)
 
 
 def _install_miopen_find_db(force=False):
@@ -40,8 +48,8 @@ def _install_miopen_find_db(force=False):
         if not files:
             return None
         default_dir = _os.path.join(_os.path.expanduser("~"), ".config", "miopen")
-        if _os.path.isdir(default_dir) and any(f.endswith(".ufdb.txt") for f in _os.listdir(default_dir)):
-            return None                                   # the user's own tuning wins
+        if _os.path.isdir(default_dir) and any(f.endswith((".ufdb.txt", ".udb.txt")) for f in _os.listdir(default_dir)):
+            return None                                   # the user's own tuning (find-db OR perf-db) wins: MIOPEN_USER_DB_PATH moves both
         dst = _os.path.join(_os.path.expanduser("~"), ".cache", "kccotgan_amd", "miopen_db")
         _os.makedirs(dst, exist_ok=True)
         for f in files:
@@ -61,4 +69,4 @@ from . import _lib            # noqa: F401,E402  (loads the HIP library)
 from . import gan_utils       # noqa: F401,E402
 from . import data_utils      # noqa: F401,E402
 
-__version__ = "0.2.1"
+__version__ = "0.3.0"

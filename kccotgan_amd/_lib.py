@@ -30,6 +30,10 @@ _i, _i64, _f, _u, _sz = _c.c_int, _c.c_int64, _c.c_float, _c.c_uint, _c.c_size_t
 SIGNATURES = {
     "kccot_version": (_i, []),
     "kccot_last_error": (_c.c_char_p, []),
+    "kccot_set_option": (_i, [_c.c_char_p, _i]),
+    "kccot_get_option": (_i, [_c.c_char_p, _c.POINTER(_i)]),
+    "kccot_option_count": (_i, []),
+    "kccot_option_name": (_c.c_char_p, [_i]),
     "kccot_pairwise_cost_workspace_bytes": (_sz, [_i, _i, _i64]),
     "kccot_pairwise_cost_f32": (_i, [_fp, _fp, _i, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _u, _fp, _fp, _sz, _fp]),
     "kccot_pairwise_cost3_workspace_bytes": (_sz, [_i, _i64]),
@@ -150,6 +154,40 @@ def check(rc, what):
     if rc == EUNSUPPORTED:
         raise NotImplementedError("%s: %s" % (what, msg))
     raise KccotError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def set_option(name, value):
+    """kccot_set_option (include/kccot.h lists the options).  Process-wide."""
+    check(lib.kccot_set_option(name.encode(), int(value)), "set_option(%s)" % name)
+
+
+def get_option(name):
+    v = _i(0)
+    check(lib.kccot_get_option(name.encode(), ctypes.byref(v)), "get_option(%s)" % name)
+    return v.value
+
+
+def option_names():
+    return [lib.kccot_option_name(k).decode() for k in range(lib.kccot_option_count())]
+
+
+class options:
+    """``with options(sinkhorn_shortcut=0, gram_f32=1): ...`` -- set, run, restore (tests, bench, A/B tools)."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def require_gpu(t):

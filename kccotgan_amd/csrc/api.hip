@@ -23,11 +23,13 @@ static const OptDesc g_desc[OPT_COUNT] = {
     {"gram_f32", 0, 0, 1},
     {"apply_f32", 0, 0, 1},
     {"cost_tiled", 1, 0, 1},
+    {"cost_tile256", 1, 0, 1},
     {"cost_blocked", 1, 0, 1},
     {"apply_m256", 1, 0, 1},
     {"sinkhorn_shortcut", 1, 0, 1},
     {"sinkhorn_fused", 1, 0, 1},
     {"sinkhorn_fused_max_n", 64, 1, 128},
+    {"sinkhorn_lanes_per_line", 0, 0, 16},
     {"sinkhorn_coop", 1, 0, 1},
     {"sinkhorn_coop_max_wg", 0, 0, 1 << 20},
     {"smooth_stream", 1, 0, 1},

@@ -11,6 +11,7 @@
 // For the loss (gan_utils.py:221-223) fake is y in the xy term and both x and y in the yy term:
 //     dfake_m = 2sc( cs_xy[m] y_m - sum_i gxy[i,m] x_i ) + 2sc( (rs_yy[m]+cs_yy[m]) y_m - sum_r (gyy[m,r]+gyy[r,m]) y_r )
 #include "common.h"
+#include "options.h"
 
 namespace kccot {
 
@@ -496,10 +497,6 @@ __global__ __launch_bounds__(256) void retile_coeffs(const unsigned short* __res
     *reinterpret_cast<uint4*>(Wt3 + dst) = v;
 }
 
-// DIAG (diagnostic builds of the SAME kernel, selected by KCCOT_APPLY_DIAG, results are then WRONG -- timing only):
-// bit 0: the consumers read the staged fragments once per chunk instead of once per k-step; bit 1: they load their W
-// fragments once per tile; bit 2: the producers skip the split and the LDS writes.
-template <int DIAG>
 __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short* __restrict__ W3, int Bt, int Rt,
                                                             const float* __restrict__ src1, int n1,
                                                             const float* __restrict__ src2, int n2, int64_t K,
@@ -532,7 +529,6 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
         auto split_stage = [&](const float4 (&src)[8], unsigned char* zb) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (DIAG & 4) { if (src[2 * i].x == 123456.f) zb[0] = 1; continue; }
                 const int r = 2 * (rp0 + 16 * i);
                 const float a[4] = {src[2 * i].x, src[2 * i].y, src[2 * i].z, src[2 * i].w};
                 const float b[4] = {src[2 * i + 1].x, src[2 * i + 1].y, src[2 * i + 1].z, src[2 * i + 1].w};
@@ -620,15 +616,15 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
                 // back down to their first use (it did: L2 latency landed on every MFMA group)
                 int gn = c * 8 + s + 3;
                 if (gn >= nsteps) gn -= nsteps;
-                if (!(DIAG & 2)) ldA(gn, (s + 3) & 3);
-                if (s < 7 && !(DIAG & 1)) ldB(s + 1, (s + 1) & 1);
+                ldA(gn, (s + 3) & 3);
+                if (s < 7) ldB(s + 1, (s + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // product-major order over the four accumulators (no MFMA waits on the one before it), smallest terms first
 #define KCCOT_A4(PA, PB)                                                                                              \
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(DIAG & 2) ? 0 : (s & 3)][0][PA], Bf[(DIAG & 1) ? 0 : (s & 1)][0][PB], acc00, 0, 0, 0); \
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(DIAG & 2) ? 0 : (s & 3)][0][PA], Bf[(DIAG & 1) ? 0 : (s & 1)][1][PB], acc01, 0, 0, 0); \
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(DIAG & 2) ? 0 : (s & 3)][1][PA], Bf[(DIAG & 1) ? 0 : (s & 1)][0][PB], acc10, 0, 0, 0); \
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(DIAG & 2) ? 0 : (s & 3)][1][PA], Bf[(DIAG & 1) ? 0 : (s & 1)][1][PB], acc11, 0, 0, 0);
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][0][PA], Bf[s & 1][0][PB], acc00, 0, 0, 0); \
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][0][PA], Bf[s & 1][1][PB], acc01, 0, 0, 0); \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][1][PA], Bf[s & 1][0][PB], acc10, 0, 0, 0); \
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][1][PA], Bf[s & 1][1][PB], acc11, 0, 0, 0);
                 KCCOT_A4(1, 1) KCCOT_A4(0, 2) KCCOT_A4(2, 0) KCCOT_A4(0, 1) KCCOT_A4(1, 0) KCCOT_A4(0, 0)
 #undef KCCOT_A4
                 __builtin_amdgcn_sched_barrier(0);
@@ -799,8 +795,8 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
                         int64_t K, float* out, hipStream_t st, const unsigned short* W3 = nullptr, int Bt = 0, int Rt = 0,
                         const unsigned short* W3base = nullptr, unsigned short* Wt3 = nullptr) {
     const bool al = (K % 4 == 0) && ((uintptr_t)s1 % 16 == 0) && (n2 == 0 || (uintptr_t)s2 % 16 == 0);
-    const char* f32env = getenv("KCCOT_APPLY_F32");           // =1: the f32-input MFMA kernel (A/B and parity runs)
-    const bool x3 = al && W3 && (n1 + n2) % 16 == 0 && Rt % 8 == 0 && ((uintptr_t)W3 % 16 == 0) && !(f32env && atoi(f32env) == 1);
+    // option "apply_f32" = 1: the f32-input MFMA kernel (parity runs)
+    const bool x3 = al && W3 && (n1 + n2) % 16 == 0 && Rt % 8 == 0 && ((uintptr_t)W3 % 16 == 0) && !opt(OPT_APPLY_F32);
     if (al) {
         // MFMA kernel on blocks: 64 output rows x (up to) 128 stack rows at a time.  One block covers the
         // BASELINE configs[1] batch in a single launch; larger batches run (Bout/64) x (R/128) launches, the
@@ -808,9 +804,9 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
         const int64_t ntiles = (K + AM_COLS - 1) / AM_COLS;
         const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);   // 2 workgroups per CU (VGPR-limited)
         const int R = n1 + n2;
-        // large batches: 256-row output tiles over the whole stack, one launch (KCCOT_APPLY_NO_M256=1: the block form)
+        // large batches: 256-row output tiles over the whole stack, one launch (option "apply_m256" = 0: the block form)
         if (x3 && Wt3 && Bout % AB_MT == 0 && Bt % 32 == 0 && n1 % AM_ROWS == 0 && n2 % AM_ROWS == 0 && R == Rt &&
-            !getenv("KCCOT_APPLY_NO_M256")) {
+            opt(OPT_APPLY_M256)) {
             const unsigned gxb = (unsigned)(ntiles < 256 ? ntiles : 256);
             // W3 is positioned at the first wanted output row (a multiple of 256 here): retile from the plane base
             const int64_t row0 = (W3 - W3base) / Rt;
@@ -821,31 +817,15 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
             const unsigned short* Wuse = Wt3 + (row0 / 32) * (int64_t)(Rt / 16) * 512;
             // 128-column tiles (half the W bytes per MFMA) once there are >= 20 of them per workgroup -- below that the
             // tail of the persistent tile loop costs more than the W stream saves (B = 256, K = 368 640: 0.73 vs 0.68 ms;
-            // B = 512, K = 2.36 M: 13.2 vs 13.8 ms).  KCCOT_APPLY_M256_N64=1 / =0 force the 64- / 128-column form.
-            const char* n64 = getenv("KCCOT_APPLY_M256_N64");
+            // B = 512, K = 2.36 M: 13.2 vs 13.8 ms).
             const int64_t nt128 = (K + AY_COLS - 1) / AY_COLS;
-            const bool wide = n64 ? atoi(n64) == 0 : nt128 >= 20 * 256;
-            if (wide && n1 % AY_ROWS == 0 && n2 % AY_ROWS == 0) {
+            if (nt128 >= 20 * 256 && n1 % AY_ROWS == 0 && n2 % AY_ROWS == 0) {
                 const unsigned gy = (unsigned)(nt128 < 256 ? nt128 : 256);
                 hipLaunchKernelGGL(apply_coeffs_x3_m256n128, dim3(gy, Bout / AB_MT), dim3(512), 0, st, Wuse, Bt, Rt, s1, n1, s2, n2,
                                    K, nt128, out);
                 return launch_status("apply_coeffs_x3_m256n128");
             }
-#ifdef KCCOT_DIAG   // libkccot_diag.so only: timing experiments with WRONG results (see the kernel's header)
-            const char* dg = getenv("KCCOT_APPLY_DIAG");
-            const int diag = dg ? atoi(dg) : 0;
-#else
-            const int diag = 0;
-#endif
-#define KCCOT_M256(D) hipLaunchKernelGGL(apply_coeffs_x3_m256<D>, dim3(gxb, Bout / AB_MT), dim3(512), 0, st, Wuse, Bt, Rt, s1, n1, s2, n2, K, ntiles, out)
-            switch (diag) {
-#ifdef KCCOT_DIAG
-                case 1: KCCOT_M256(1); break; case 2: KCCOT_M256(2); break; case 3: KCCOT_M256(3); break;
-                case 4: KCCOT_M256(4); break; case 7: KCCOT_M256(7); break;
-#endif
-                default: KCCOT_M256(0); break;
-            }
-#undef KCCOT_M256
+            hipLaunchKernelGGL(apply_coeffs_x3_m256, dim3(gxb, Bout / AB_MT), dim3(512), 0, st, Wuse, Bt, Rt, s1, n1, s2, n2, K, ntiles, out);
             return launch_status("apply_coeffs_x3_m256");
         }
         for (int ob = 0; ob < Bout; ob += 64) {

@@ -25,7 +25,7 @@
 // not care in which order the eight k of a group are visited.
 #include "common.h"
 #include "cost_internal.h"
-#include <stdlib.h>
+#include "options.h"
 
 namespace kccot {
 
@@ -282,100 +282,6 @@ __device__ __forceinline__ void split3_store(unsigned char* zs, int byte_off, fl
     *reinterpret_cast<uint2*>(zs + 2 * XPLANE + byte_off) = pl;
 }
 
-#define KCCOT_X3(ACC, AOFF, BOFF)                                                               \
-    {                                                                                           \
-        const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(zs + (AOFF));                        \
-        const bf16x8 Am = *reinterpret_cast<const bf16x8*>(zs + XPLANE + (AOFF));               \
-        const bf16x8 Al = *reinterpret_cast<const bf16x8*>(zs + 2 * XPLANE + (AOFF));           \
-        const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(zs + (BOFF));                        \
-        const bf16x8 Bm = *reinterpret_cast<const bf16x8*>(zs + XPLANE + (BOFF));               \
-        const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(zs + 2 * XPLANE + (BOFF));           \
-        /* smallest terms first */                                                              \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, ACC, 0, 0, 0);                    \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, ACC, 0, 0, 0);                    \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, ACC, 0, 0, 0);                    \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, ACC, 0, 0, 0);                    \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, ACC, 0, 0, 0);                    \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, ACC, 0, 0, 0);                    \
-    }
-
-__global__ __launch_bounds__(256) void gram128_partial_x3(GramArgs ga) {
-    __shared__ __attribute__((aligned(16))) unsigned char zs[3 * XPLANE];
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int64_t kbeg = (int64_t)blockIdx.x * ga.chunk;
-    const int64_t kend = (kbeg + ga.chunk < ga.K) ? kbeg + ga.chunk : ga.K;
-    if (kbeg >= kend) return;
-
-    // staging: thread holds the float4 at columns c4..c4+3 of stack rows r0 + 16 j (j < 4: src1,
-    // j >= 4: src2 row r0 + 16 (j-4)) -- row i of both tensors in one thread, for E = src2 - src1
-    const int r0 = t >> 4, c4 = (t & 15) * 4;
-    const float* rp[8];
-    bool ok[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = r0 + 16 * (j & 3);
-        ok[j] = r < (j < 4 ? ga.n1 : ga.n2);
-        rp[j] = (j < 4 ? ga.src1 : ga.src2) + (int64_t)r * ga.K;
-    }
-    const WaveWork ww = wave_work(0x3FFu, wave);
-    const int lo = (lane & 31) * XPITCH + 16 * (lane >> 5);     // row (lane&31), k half (lane>>5) of a 16-k block
-    const int a0 = ww.a[0] * 32 * XPITCH + lo, b0 = ww.b[0] * 32 * XPITCH + lo;
-    const int a1 = ww.a[1] * 32 * XPITCH + lo, b1 = ww.b[1] * 32 * XPITCH + lo;
-    const int a2 = ww.a[2] * 32 * XPITCH + lo, b2 = ww.b[2] * 32 * XPITCH + lo;
-    const int half = (wave & 1) * 2;                            // k-blocks of the split sub-tile
-
-    f32x16 acc0, acc1, acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
-
-    float4 v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kbeg + c4, kend, ok[j]);
-
-    for (int64_t k0 = kbeg; k0 < kend; k0 += XKT) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (ga.pair_diff) {
-                v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
-            }
-            split3_store(zs, (r0 + 16 * j) * XPITCH + c4 * 2, v[j]);
-            split3_store(zs, (64 + r0 + 16 * j) * XPITCH + c4 * 2, v[j + 4]);
-        }
-        __syncthreads();
-        const int64_t kn = k0 + XKT;
-        if (kn < kend) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kn + c4, kend, ok[j]);
-        }
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            KCCOT_X3(acc0, a0 + kb * 32, b0 + kb * 32)
-            KCCOT_X3(acc1, a1 + kb * 32, b1 + kb * 32)
-        }
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            KCCOT_X3(acc2, a2 + (half + g) * 32, b2 + (half + g) * 32)
-        }
-        __syncthreads();
-    }
-
-    float* base = ga.gpart + (int64_t)blockIdx.x * GRAM_SLABS * 1024;
-    const int col = lane & 31, rbase = 4 * (lane >> 5);
-    {
-        float* o = base + ww.slab[0] * 1024;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc0[r];
-        o = base + ww.slab[1] * 1024;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc1[r];
-        o = base + ww.slab[2] * 1024;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc2[r];
-    }
-}
-
 // ---- consumer side of the wave-specialised kernel -------------------------------------------------
 // One ds_read_b128 moves 1 KB = 8 cycles of the CU's LDS port, one bf16 MFMA keeps a SIMD's matrix
 // pipe busy for 32 cycles and four consumer waves run concurrently: at one fragment read per MFMA
@@ -437,9 +343,6 @@ __device__ __forceinline__ void x3ws_consume(const unsigned char* zsA, const uns
         const unsigned char* zs = (s & 1) ? zsB : zsA;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-#if defined(KCCOT_GRAM_EXP) && KCCOT_GRAM_EXP == 1
-            continue;   // diagnostic build: consumers only keep the barriers (producer-limited time)
-#endif
             const Frag3 fx = ld_frag3(zs, ox + kb * 32), fy = ld_frag3(zs, oy + kb * 32);
             mfma_x3(acc0, fx, fx);
             if (W != 3) mfma_x3(acc1, fx, fy); else mfma_x3(acc1, fy, fx);      // (X,Y), or (0,3) = (Y,X) for W = 3
@@ -516,7 +419,13 @@ __device__ __forceinline__ void x3ws_produce_deep_impl(const GramArgs& ga, unsig
     const bool pd = ga.pair_diff;
     DeepSet v, w;
     x3ws_issue(v, rp, koff(0));
-    x3ws_issue(w, rp, koff(1));                                           // nstage >= 2 (caller)
+    if (nstage < 2) {                                                     // a chunk of a single stage
+        x3ws_emit<true>(v, ok, kok(0), pd, zsA, wbase);
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
+    x3ws_issue(w, rp, koff(1));
     int s = 0;
     for (; s + 3 < nstage; s += 2) {
         x3ws_emit<MASK>(v, ok, kok(s), pd, zsA, wbase);
@@ -546,15 +455,10 @@ __device__ __forceinline__ void x3ws_produce_deep(const GramArgs& ga, unsigned c
                                                   int64_t kbeg, int64_t kend, int nstage) {
     // uniform: full row blocks and whole stages need no masking at all
     const bool whole = ga.n1 == 64 && ga.n2 == 64 && kend - kbeg == (int64_t)nstage * XKT;
-#if defined(KCCOT_GRAM_EXP) && KCCOT_GRAM_EXP == 2
-    for (int s = 0; s <= nstage; ++s) __syncthreads();   // diagnostic build: producers only keep the barriers
-    return;
-#endif
     if (whole) x3ws_produce_deep_impl<false>(ga, zsA, zsB, t, kbeg, kend, nstage);
     else x3ws_produce_deep_impl<true>(ga, zsA, zsB, t, kbeg, kend, nstage);
 }
 
-template <bool gram_two_deep>
 __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
     __shared__ __attribute__((aligned(16))) unsigned char zsA[3 * XPLANE];
     __shared__ __attribute__((aligned(16))) unsigned char zsB[3 * XPLANE];
@@ -578,53 +482,7 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
 
     if (wave < 4) {
         // ------------------------------------------------------------------ producers
-        if (gram_two_deep && nstage >= 2) {
-            x3ws_produce_deep(ga, zsA, zsB, t, kbeg, kend, nstage);
-            return;
-        }
-        const int r0 = t >> 4, c4 = (t & 15) * 4;
-        const float* rp[8];
-        bool ok[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = r0 + 16 * (j & 3);
-            ok[j] = r < (j < 4 ? ga.n1 : ga.n2);
-            rp[j] = (j < 4 ? ga.src1 : ga.src2) + (int64_t)r * ga.K;
-        }
-        const int wbase = r0 * XPITCH + c4 * 2;
-        // one stage of loads in flight (predicated loads; chunks of a single stage, and the A/B reference for the deep form)
-        float4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kbeg + c4, kend, ok[j]);
-        for (int s = 0; s <= nstage; ++s) {
-            // stage s goes into buffer s&1 (the consumers read it during iteration s+1 of this loop)
-#if defined(KCCOT_GRAM_EXP) && KCCOT_GRAM_EXP == 2
-            if (false) {   // diagnostic build: producers only keep the barriers (consumer-limited time)
-#else
-            if (s < nstage) {
-#endif
-                unsigned char* zb = (s & 1) ? zsB : zsA;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#if defined(KCCOT_GRAM_EXP) && KCCOT_GRAM_EXP == 3
-                    // diagnostic build: global loads only, one cheap use so that they are not dropped
-                    if (v[j].x + v[j + 4].x == 1234.5f) zb[wbase] = 1;
-                    continue;
-#endif
-                    if (ga.pair_diff) {
-                        v[j + 4].x -= v[j].x; v[j + 4].y -= v[j].y; v[j + 4].z -= v[j].z; v[j + 4].w -= v[j].w;
-                    }
-                    split3_store(zb, wbase + 16 * j * XPITCH, v[j]);
-                    split3_store(zb, wbase + (64 + 16 * j) * XPITCH, v[j + 4]);
-                }
-                if (s + 1 < nstage) {
-                    const int64_t kn = kbeg + (int64_t)(s + 1) * XKT;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = ld4(rp[j], kn + c4, kend, ok[j]);
-                }
-            }
-            __syncthreads();
-        }
+        x3ws_produce_deep(ga, zsA, zsB, t, kbeg, kend, nstage);
         return;
     }
 
@@ -787,16 +645,9 @@ bool gram_preferred(const CostBatch& cb, int64_t K, bool loss3) {
     return gram_eligible(cb, K, loss3) && K >= 256;
 }
 
-static int gram_target_wgs() {
-    const char* e = getenv("KCCOT_GRAM_WGS");   // tuning knob (bench sweeps)
-    int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 256;
-}
+static int gram_target_wgs() { return 256; }
 
-static bool gram_use_x3() {
-    const char* e = getenv("KCCOT_GRAM_F32");   // =1: keep the f32-input MFMA kernel (A/B and parity runs)
-    return !(e && atoi(e) == 1);
-}
+static bool gram_use_x3() { return !opt(OPT_GRAM_F32); }   // option "gram_f32" = 1: the f32-input MFMA kernel (parity runs)
 
 GramPlan plan_gram(int64_t K) {
     GramPlan pl{};
@@ -897,19 +748,13 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
         return launch_status("gram_finalize");
     }
     if (ga.mask == 0x3FFu && gram_use_x3()) {
-        const char* e = getenv("KCCOT_GRAM_WS");   // =0: the single-role x3 kernel (A/B)
-        if (e && atoi(e) == 0) hipLaunchKernelGGL(gram128_partial_x3, dim3(pl.nchunk), dim3(256), 0, st, ga);
-        else {
-            // 16 spare workgroups (one per CU the 240-way K-split leaves idle) take the causal tiles
-            int spare = 0;
-            if (ncausal > 0 && !partial_only) { spare = ncausal < 16 ? ncausal : 16; ga.ntiles = ncausal; ncausal = 0; }
-            // two stages of loads in flight (unconditional clamped loads, x3ws_produce_deep): 19.1-20.4 us against
-            // 21.0-21.8 us for one stage with predicated loads (KCCOT_GRAM_DEEP=0, kept as the A/B reference)
-            const char* d = getenv("KCCOT_GRAM_DEEP");
-            if (!d || atoi(d) != 0) hipLaunchKernelGGL(gram128_partial_x3ws<true>, dim3(pl.nchunk + spare), dim3(512), 0, st, ga);
-            else hipLaunchKernelGGL(gram128_partial_x3ws<false>, dim3(pl.nchunk + spare), dim3(512), 0, st, ga);
-            split_mode = GRAM_SPLIT_26;
-        }
+        // 16 spare workgroups (one per CU the 240-way K-split leaves idle) take the causal tiles
+        int spare = 0;
+        if (ncausal > 0 && !partial_only) { spare = ncausal < 16 ? ncausal : 16; ga.ntiles = ncausal; ncausal = 0; }
+        // (producers with two stages of unconditional clamped loads in flight: 19.1-20.4 us against 21.0-21.8 us for one
+        // stage of predicated loads, profiles/r02x_ab_gram_producers.txt)
+        hipLaunchKernelGGL(gram128_partial_x3ws, dim3(pl.nchunk + spare), dim3(512), 0, st, ga);
+        split_mode = GRAM_SPLIT_26;
     }
     else if (ga.mask == 0x3FFu) hipLaunchKernelGGL(gram128_partial<true>, dim3(pl.nchunk), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL(gram128_partial<false>, dim3(pl.nchunk), dim3(256), 0, st, ga);
@@ -937,7 +782,7 @@ namespace kccot {
 // (J,I); xx and yy are symmetric in their distances, so one launch per unordered pair writes the block and, with
 // the mirror block's own causal term, its transpose.  nb + 2 nb (nb - 1) launches of three kernels each.
 bool gram_blocked_eligible(const CostBatch& cb, int64_t K, bool loss3) {
-    if (!loss3 || cb.nprob != 3 || !gram_use_x3() || getenv("KCCOT_COST_NO_BLOCKED")) return false;
+    if (!loss3 || cb.nprob != 3 || !gram_use_x3() || !opt(OPT_COST_BLOCKED)) return false;
     const int B = cb.p[0].Bx;
     if (B <= 64 || B % 64 != 0 || cb.p[0].By != B || K % 4 != 0 || K < 256) return false;
     for (int p = 0; p < 3; ++p)

@@ -432,7 +432,9 @@ void gram_q256_sums_span(int B, int64_t K, size_t* off, size_t* n) {
 
 size_t gram_q256_workspace_bytes(int B, int64_t K) { return q256_shape_ok(B, K) ? plan_q256(B, K).ws_bytes : 0; }
 
-bool gram_q256_applies(int B, int64_t K) { return q256_shape_ok(B, K) && opt(OPT_COST_TILED) && !opt(OPT_GRAM_F32); }
+bool gram_q256_applies(int B, int64_t K) {
+    return q256_shape_ok(B, K) && opt(OPT_COST_TILED) && opt(OPT_COST_TILE256) && !opt(OPT_GRAM_F32);
+}
 
 bool gram_q256_eligible(const CostBatch& cb, int64_t K, bool loss3) {
     if (!loss3 || cb.nprob != 3) return false;

@@ -1,4 +1,5 @@
-// The loss's three cost matrices for batches of 128, 256, 384, ... (B % 128 == 0): ONE Gram matrix of the 2B-row
+// The loss's three cost matrices for batches of 128, 384, 640, ... (B % 128 == 0 that cost_tile256.hip's 256-row tiles do
+// not take: B % 256 != 0, or the option "cost_tile256" = 0): ONE Gram matrix of the 2B-row
 // stack S = [real ; E], E = fake - real (the pair-difference form of cost_mfma.hip, gan_utils.py:221-223), produced
 // in 128 x 128 tiles on the bf16 matrix pipe with the exact three-way split.
 //
@@ -16,7 +17,7 @@
 //                     indices), scale, causal term (causal_tile16)
 #include "common.h"
 #include "cost_internal.h"
-#include <stdlib.h>
+#include "options.h"
 
 namespace kccot {
 
@@ -37,54 +38,8 @@ struct TileArgs {
     int B, nt, nchunk;
     int64_t K, chunk;
     float* part;      // [npairs][nchunk][TELEMS]
-    const unsigned short* planes;   // PLANES build: pre-split stack [3][2B][K] bf16 (presplit_stack), else null
     const float* ediff;             // E = fake - real [B][K] formed ONCE (ediff_rows), or null: E panels subtract while staging
 };
-
-// ---- one-time exact three-way split of the stack [real ; fake - real] into bf16 planes (round 2) ---------------------
-// gram_tile_x3's producers fetched, subtracted, split and staged every panel chunk once per PAIR it takes part in
-// (B = 512: 9 times), and the SQ counters showed the kernel parked on them (59 % of all wave cycles in s_waitcnt /
-// barrier, 27 % matrix-pipe utilisation at B = 512).  Memory is plentiful (288 GB): the stack is cut ONCE into its three
-// planes P[pl][row][k] (6 bytes per element: 14.5 GB at configs[4], 1.1 GB at configs[3]) and the Gram kernel's
-// producers become plain 16-byte copies.  Same pieces bit for bit (tsplit3_store's arithmetic), same MFMAs: identical sums.
-__global__ __launch_bounds__(256) void presplit_stack(const float* __restrict__ real, const float* __restrict__ fake, int B,
-                                                      int64_t K, unsigned short* __restrict__ planes) {
-    const int64_t groups_per_row = K >> 3;                       // 8 consecutive k per thread (K % 8 == 0)
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (int64_t)2 * B * groups_per_row) return;
-    const int64_t row = e / groups_per_row, k = (e - row * groups_per_row) << 3;
-    float v[8];
-    if (row < B) {
-        const float4 a = *reinterpret_cast<const float4*>(real + row * K + k), b = *reinterpret_cast<const float4*>(real + row * K + k + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
-        const int64_t o = (row - B) * K + k;
-        const float4 a = *reinterpret_cast<const float4*>(fake + o), b = *reinterpret_cast<const float4*>(fake + o + 4);
-        const float4 c = *reinterpret_cast<const float4*>(real + o), d = *reinterpret_cast<const float4*>(real + o + 4);
-        v[0] = a.x - c.x; v[1] = a.y - c.y; v[2] = a.z - c.z; v[3] = a.w - c.w;
-        v[4] = b.x - d.x; v[5] = b.y - d.y; v[6] = b.z - d.z; v[7] = b.w - d.w;
-    }
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const unsigned x = __float_as_uint(v[i]);
-        const float hf = __uint_as_float(x & 0xFFFF0000u);
-        const float r1 = v[i] - hf;                                            // exact
-        const float mm = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
-        h[i] = x; m[i] = __float_as_uint(r1); l[i] = __float_as_uint(r1 - mm);     // pieces = the upper 16 bits of each word
-    }
-    const int64_t plane = (int64_t)2 * B * K, o = row * K + k;
-    uint4 ph, pm, pl;
-    ph.x = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u); ph.y = __builtin_amdgcn_perm(h[3], h[2], 0x07060302u);
-    ph.z = __builtin_amdgcn_perm(h[5], h[4], 0x07060302u); ph.w = __builtin_amdgcn_perm(h[7], h[6], 0x07060302u);
-    pm.x = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); pm.y = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
-    pm.z = __builtin_amdgcn_perm(m[5], m[4], 0x07060302u); pm.w = __builtin_amdgcn_perm(m[7], m[6], 0x07060302u);
-    pl.x = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u); pl.y = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
-    pl.z = __builtin_amdgcn_perm(l[5], l[4], 0x07060302u); pl.w = __builtin_amdgcn_perm(l[7], l[6], 0x07060302u);
-    *reinterpret_cast<uint4*>(planes + o) = ph;
-    *reinterpret_cast<uint4*>(planes + plane + o) = pm;
-    *reinterpret_cast<uint4*>(planes + 2 * plane + o) = pl;
-}
 
 // E = fake - real once, in fp32 (the same subtraction the producers do while staging: bit-identical sums).  Why it pays
 // for large batches: the tile kernel is bound by the bytes its workgroups pull through L2 (PMC: 3.3x the algorithmic
@@ -254,10 +209,6 @@ __device__ __forceinline__ void tile_produce(const float* am, const float* as, c
 // consumer wave share each SIMD, whose VALU and matrix pipe run concurrently.  One barrier per 32-k stage.
 // (The first version did both roles in every wave with one wave per SIMD: the split sat between the MFMA phases
 // and B = 512 ran slower than the blocked path.)
-// DIAG (KCCOT_GRAM_TILE_DIAG, timing experiments on the PLANES build only, results are WRONG): bit 0 = the producers
-// issue no global loads; bit 1 = the consumers read their fragments once per stage instead of once per 16-k block;
-// bit 2 = no MFMAs.
-template <bool PLANES, int DIAG = 0>
 __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
     __shared__ __attribute__((aligned(16))) unsigned char zsA[TBUF];
     __shared__ __attribute__((aligned(16))) unsigned char zsB[TBUF];
@@ -279,56 +230,6 @@ __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
     if (kbeg >= kend) return;
     const int nstage = (int)((kend - kbeg + TK - 1) / TK);
 
-    if (PLANES && wave < 4) {
-        // ------------------------------------------------------------------ producers, pre-split planes: pure copies.
-        // thread: rows r0 and r0 + 64 of each panel, the 8 k at c8 of the 32-k stage, all three planes
-        const int r0 = t >> 2, c8 = (t & 3) * 8;
-        const int64_t plane = (int64_t)2 * ta.B * K;
-        const unsigned short* pA = ta.planes + ((int64_t)pa * TP + r0) * K + c8;
-        const unsigned short* pB = ta.planes + ((int64_t)pb * TP + r0) * K + c8;
-        const int wbase = r0 * TPITCH + c8 * 2;
-        struct StageP { uint4 a[2][3], b[2][3]; };
-        StageP s0, s1;
-        auto ld = [&](const unsigned short* q, int64_t k0) {
-            if (DIAG & 1) return make_uint4((unsigned)k0, 1u, 2u, 3u);
-            return (k0 + c8 + 8 <= kend) ? *reinterpret_cast<const uint4*>(q + k0) : make_uint4(0u, 0u, 0u, 0u);
-        };
-        auto load_stage = [&](StageP& g, int64_t k0) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    g.a[j][pl] = ld(pA + pl * plane + (int64_t)j * 64 * K, k0);
-                    if (!same) g.b[j][pl] = ld(pB + pl * plane + (int64_t)j * 64 * K, k0);
-                }
-        };
-        auto store_stage = [&](const StageP& g, unsigned char* zb) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    *reinterpret_cast<uint4*>(zb + pl * TPLANE + wbase + 64 * j * TPITCH) = g.a[j][pl];
-                    if (!same) *reinterpret_cast<uint4*>(zb + pl * TPLANE + wbase + (TP + 64 * j) * TPITCH) = g.b[j][pl];
-                }
-        };
-        load_stage(s0, kbeg);
-        if (nstage > 1) load_stage(s1, kbeg + TK);
-        for (int s = 0; s <= nstage; s += 2) {
-            if (s < nstage) {
-                store_stage(s0, zsA);
-                if (s + 2 < nstage) load_stage(s0, kbeg + (int64_t)(s + 2) * TK);
-            }
-            __syncthreads();
-            if (s + 1 <= nstage) {
-                if (s + 1 < nstage) {
-                    store_stage(s1, zsB);
-                    if (s + 3 < nstage) load_stage(s1, kbeg + (int64_t)(s + 3) * TK);
-                }
-                __syncthreads();
-            }
-        }
-        return;
-    }
     if (wave < 4) {
         // ------------------------------------------------------------------ producers (in-kernel split)
         const float *am, *as, *bm, *bs;
@@ -374,10 +275,8 @@ __global__ __launch_bounds__(512) void gram_tile_x3(TileArgs ta) {
         const unsigned char* zs = (s & 1) ? zsB : zsA;
 #pragma unroll
         for (int kb = 0; kb < TK / 16; ++kb) {
-            const int kq = (DIAG & 2) ? 0 : kb;
-            const TFrag a0 = tld_frag(zs, aoff0 + kq * 32), a1 = tld_frag(zs, aoff1 + kq * 32);
-            const TFrag b0 = tld_frag(zs, boff0 + kq * 32), b1 = tld_frag(zs, boff1 + kq * 32);
-            if (DIAG & 4) { acc00[0] += (float)a0.h[0] + (float)a1.m[0] + (float)b0.l[0] + (float)b1.h[0]; continue; }
+            const TFrag a0 = tld_frag(zs, aoff0 + kb * 32), a1 = tld_frag(zs, aoff1 + kb * 32);
+            const TFrag b0 = tld_frag(zs, boff0 + kb * 32), b1 = tld_frag(zs, boff1 + kb * 32);
             // product-major order: the four accumulators take turns, so no MFMA waits on the one issued before it
 #define KCCOT_T4(PA, PB)                                                                             \
             acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.PA, b0.PB, acc00, 0, 0, 0);               \
@@ -473,26 +372,11 @@ __global__ __launch_bounds__(256) void gram_tile_finalize(TileFin f) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-struct TilePlan { int nt, npairs, nchunk; int64_t chunk; size_t part_bytes, gsum_bytes, planes_bytes, ediff_bytes, ws_bytes; };
+struct TilePlan { int nt, npairs, nchunk; int64_t chunk; size_t part_bytes, gsum_bytes, ediff_bytes, ws_bytes; };
 
-// E = fake - real materialised once for B >= 512 (KCCOT_GRAM_EDIFF_MINB overrides; 0 = never).  Measured cost stage, the
-// extra pass included (tools/ab_ediff.sh, profiles/r03ac_ab_ediff.txt): B = 512 (K = 2.36 M) 22.6 -> 21.1-21.3 ms (the tile
-// kernel alone 22.6 -> ~18.3 ms) for 4.8 GB more workspace; B = 384 equal (2.14 vs 2.13 ms); B = 256 SLOWER (1.12 vs 1.04 ms)
-static bool tiled_ediff(int B) {
-    int minb = 512;
-    if (const char* e = getenv("KCCOT_GRAM_EDIFF_MINB")) minb = atoi(e);
-    return minb > 0 && B >= minb;
-}
-
-// Pre-split planes are OPT-IN (KCCOT_GRAM_PRESPLIT=1): measured slower than the in-kernel split (B = 256: 1.38 vs 1.22 ms
-// for the cost stage, B = 512: 31.2 vs 26.7 ms).  The diagnostic builds showed why: with the planes the kernel itself
-// takes exactly as long as before (its producers were never the limit) and the extra pass is pure overhead -- the tile
-// kernel is bound by the bytes it pulls through L2 (B = 512: 13.6 of its 26.7 ms disappear when the producers issue no
-// loads; without MFMAs it still takes 76 % of its time), and planes are 6 bytes per element where fp32 is 4.
-static bool tiled_presplit(int B, int64_t K) {
-    const char* f = getenv("KCCOT_GRAM_PRESPLIT");
-    return f && atoi(f) == 1 && !getenv("KCCOT_GRAM_NO_PRESPLIT") && B >= 128 && K % 8 == 0;
-}
+// E = fake - real materialised once for B >= 512.  Measured cost stage, the extra pass included (profiles/r03ac_ab_ediff.txt):
+// B = 512 (K = 2.36 M) 22.6 -> 21.1-21.3 ms for 4.8 GB more workspace; B = 384 equal; B = 256 SLOWER (1.12 vs 1.04 ms).
+static bool tiled_ediff(int B) { return B >= 512; }
 
 static TilePlan plan_tiled(int B, int64_t K) {
     TilePlan pl{};
@@ -516,7 +400,6 @@ static TilePlan plan_tiled(int B, int64_t K) {
     // shorter chunks = tighter lock-step.  Measured at B = 512, K = 2.36 M: 8 chunks per XCD 21.3 ms, 32: 20.5 ms, 64:
     // 20.4 ms (partials 0.15 / 0.6 / 1.2 GB); B = 256 does not care (1.05-1.15 ms either way).
     if (pl.npairs >= 36 && best < 32) best = 32;
-    if (const char* e = getenv("KCCOT_GRAM_TILE_CPS")) { const int v = atoi(e); if (v >= 1 && v <= 512) best = v; }   // tuning knob
     int64_t nchunk = 8 * (int64_t)best;
     while (nchunk > 8 && nchunk > ksteps) nchunk -= 8;
     const int64_t spc = (ksteps + nchunk - 1) / nchunk;
@@ -524,9 +407,8 @@ static TilePlan plan_tiled(int B, int64_t K) {
     pl.nchunk = (int)nchunk;                                  // trailing chunks may be empty (kbeg >= K): they return at once
     pl.part_bytes = align_up((size_t)pl.npairs * pl.nchunk * TELEMS * sizeof(float), 256);
     pl.gsum_bytes = align_up((size_t)pl.npairs * TELEMS * sizeof(double), 256);
-    pl.planes_bytes = tiled_presplit(B, K) ? align_up((size_t)3 * 2 * B * K * sizeof(unsigned short), 256) : 0;
-    pl.ediff_bytes = (!pl.planes_bytes && tiled_ediff(B)) ? align_up((size_t)B * K * sizeof(float), 256) : 0;
-    pl.ws_bytes = pl.part_bytes + pl.gsum_bytes + pl.planes_bytes + pl.ediff_bytes;
+    pl.ediff_bytes = tiled_ediff(B) ? align_up((size_t)B * K * sizeof(float), 256) : 0;
+    pl.ws_bytes = pl.part_bytes + pl.gsum_bytes + pl.ediff_bytes;
     return pl;
 }
 
@@ -543,9 +425,8 @@ size_t gram_tiled_workspace_bytes(int B, int64_t K) {
 }
 
 bool gram_tiled_eligible(const CostBatch& cb, int64_t K, bool loss3) {
-    if (!loss3 || cb.nprob != 3 || getenv("KCCOT_COST_NO_TILED")) return false;
-    const char* e = getenv("KCCOT_GRAM_F32");                 // the f32-input MFMA request keeps the other paths
-    if (e && atoi(e) == 1) return false;
+    if (!loss3 || cb.nprob != 3 || !opt(OPT_COST_TILED)) return false;
+    if (opt(OPT_GRAM_F32)) return false;                      // the f32-input MFMA request keeps the other paths
     const int B = cb.p[0].Bx;
     if (B < TP || B % TP != 0 || B > 4096 || cb.p[0].By != B || K % 4 != 0 || K < 256) return false;
     return ((uintptr_t)cb.p[0].x % 16 == 0) && ((uintptr_t)cb.p[0].y % 16 == 0);
@@ -562,35 +443,14 @@ int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void*
     double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.part_bytes);
     int rc;
     if (stage != 2) {
-        TileArgs ta{cb.p[0].x, cb.p[0].y, B, pl.nt, pl.nchunk, K, pl.chunk, part, nullptr, nullptr};
+        TileArgs ta{cb.p[0].x, cb.p[0].y, B, pl.nt, pl.nchunk, K, pl.chunk, part, nullptr};
         if (pl.ediff_bytes) {
             float* e = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.part_bytes + pl.gsum_bytes);
             hipLaunchKernelGGL(ediff_rows, dim3(2048), dim3(256), 0, st, cb.p[0].x, cb.p[0].y, (int64_t)B * K / 4, e);
             if ((rc = launch_status("ediff_rows"))) return rc;
             ta.ediff = e;
         }
-        if (pl.planes_bytes && tiled_presplit(B, K)) {
-            unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + pl.part_bytes + pl.gsum_bytes);
-            const int64_t ngroups = (int64_t)2 * B * (K >> 3);
-            if ((ngroups + 255) / 256 > 0x7fffffff) return fail(KCCOT_EUNSUPPORTED, "pairwise_cost3(tiled): stack too large");
-            hipLaunchKernelGGL(presplit_stack, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, cb.p[0].x, cb.p[0].y, B, K, planes);
-            if ((rc = launch_status("presplit_stack"))) return rc;
-            ta.planes = planes;
-            const dim3 gg(pl.npairs * pl.nchunk);
-#ifdef KCCOT_DIAG   // libkccot_diag.so only: timing experiments with WRONG results (see the kernel's header)
-            const char* dg = getenv("KCCOT_GRAM_TILE_DIAG");
-            const int diag = dg ? atoi(dg) : 0;
-            if (diag == 1) hipLaunchKernelGGL((gram_tile_x3<true, 1>), gg, dim3(512), 0, st, ta);
-            else if (diag == 2) hipLaunchKernelGGL((gram_tile_x3<true, 2>), gg, dim3(512), 0, st, ta);
-            else if (diag == 3) hipLaunchKernelGGL((gram_tile_x3<true, 3>), gg, dim3(512), 0, st, ta);
-            else if (diag == 4) hipLaunchKernelGGL((gram_tile_x3<true, 4>), gg, dim3(512), 0, st, ta);
-            else if (diag == 5) hipLaunchKernelGGL((gram_tile_x3<true, 5>), gg, dim3(512), 0, st, ta);
-            else
-#endif
-            hipLaunchKernelGGL((gram_tile_x3<true, 0>), gg, dim3(512), 0, st, ta);
-        } else {
-            hipLaunchKernelGGL((gram_tile_x3<false, 0>), dim3(pl.npairs * pl.nchunk), dim3(512), 0, st, ta);
-        }
+        hipLaunchKernelGGL(gram_tile_x3, dim3(pl.npairs * pl.nchunk), dim3(512), 0, st, ta);
         if ((rc = launch_status("gram_tile_x3"))) return rc;
         const int nvalid = (int)((K + pl.chunk - 1) / pl.chunk);
         hipLaunchKernelGGL(gram_tile_reduce, dim3(TELEMS / 256, pl.npairs), dim3(256), 0, st, (const float*)part, pl.nchunk, nvalid, gsum);

@@ -8,11 +8,13 @@ enum Option {
     OPT_GRAM_F32 = 0,            // "gram_f32"
     OPT_APPLY_F32,               // "apply_f32"
     OPT_COST_TILED,              // "cost_tiled"
+    OPT_COST_TILE256,            // "cost_tile256"
     OPT_COST_BLOCKED,            // "cost_blocked"
     OPT_APPLY_M256,              // "apply_m256"
     OPT_SK_SHORTCUT,             // "sinkhorn_shortcut"
     OPT_SK_FUSED,                // "sinkhorn_fused"
     OPT_SK_FUSED_MAX_N,          // "sinkhorn_fused_max_n"
+    OPT_SK_LPR,                  // "sinkhorn_lanes_per_line"
     OPT_SK_COOP,                 // "sinkhorn_coop"
     OPT_SK_COOP_MAX_WG,          // "sinkhorn_coop_max_wg"
     OPT_SMOOTH_STREAM,           // "smooth_stream"

@@ -18,7 +18,7 @@
 // u), carried in log2 units so that exp/log are the hardware v_exp_f32 / v_log_f32 (see half_step).
 #include "common.h"
 #include <math.h>
-#include <stdlib.h>
+#include "options.h"
 
 // No floating-point contraction in this file: the solver kernels exist in several forms (forward / sweep / fused,
 // different lanes per line) that are tested for BIT-identical results, and a mul + add that the compiler fuses into
@@ -803,9 +803,9 @@ static SinkGeom sink_geom(int n, bool forward) {
     // (72 us) and keeps 16.
     g.lpr = (n <= 32) ? 16 : (n <= 64 ? (forward ? 8 : 16) : 8);
     if (n > 32 && n <= 64) {
-        // tuning knob for the configs[1] size: 4, 8 or 16 lanes per line (256 / 512 / 1024 threads)
-        const char* e = getenv("KCCOT_SK_LPR");
-        const int v = e ? atoi(e) : 0;
+        // option "sinkhorn_lanes_per_line" = 4, 8 or 16 (0 = the rule above): the fused kernel runs 8, so equality tests of
+        // its gradients against the two-kernel path put both on 8
+        const int v = opt(OPT_SK_LPR);
         if (v == 4 || v == 8 || v == 16) g.lpr = v;
     }
     const int need = (n + g.lpr - 1) / g.lpr;
@@ -828,10 +828,8 @@ int launch_sinkhorn_bwd_gen(const float* C, const float* u_hist, const float* v_
 
 using namespace kccot;
 
-static int sink_shortcut_enabled() {
-    const char* e = getenv("KCCOT_SK_NO_SHORTCUT");   // =1: always execute every iteration (A/B, bitwise-equality tests)
-    return !(e && atoi(e) == 1);
-}
+// option "sinkhorn_shortcut" = 0: always execute every iteration (bench headline, bitwise-equality tests)
+static int sink_shortcut_enabled() { return opt(OPT_SK_SHORTCUT); }
 
 // set by the *_divergence_* entry points around their call into the base functions
 static thread_local float* g_div_loss = nullptr;
@@ -942,26 +940,22 @@ static size_t fused_hist_bytes(int n, int L) {
 }
 
 extern "C" int kccot_sinkhorn_fused_eligible(int n, int L) {
-    const char* e = getenv("KCCOT_SK_NO_FUSED");          // =1: always the two-kernel path (A/B, equality tests)
-    if (e && atoi(e) == 1) return 0;
+    if (!opt(OPT_SK_FUSED)) return 0;                     // option "sinkhorn_fused" = 0: always the two-kernel path
     // n <= 64 by default: at 64 < n <= 128 (16 entries per lane and orientation) the fused kernel spills under the
     // 128-VGPR cap of a 1024-thread workgroup and measured SLOWER than the two kernels at configs[2]
-    // (1.24 vs 1.08 ms per loss); KCCOT_SK_FUSED_MAXN=128 re-enables it for experiments.
-    const char* mx = getenv("KCCOT_SK_FUSED_MAXN");
-    const int maxn = mx ? atoi(mx) : 64;
+    // (1.24 vs 1.08 ms per loss); option "sinkhorn_fused_max_n" = 128 re-enables it.
+    const int maxn = opt(OPT_SK_FUSED_MAX_N);
     if (n <= 0 || n > SK_MAXN || n > maxn || L < 0) return 0;
     return fused_hist_bytes(n, L) <= (size_t)144 * 1024;  // + ~4 KB of static LDS, inside the CU's 160 KB
 }
 
 template <int EPT, int LPR, bool SC>
 static int launch_fused(const SinkFusedArgs& a, size_t lds, hipStream_t st) {
-    static bool attr_set = false;                          // one per instantiation
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_fused_reg<EPT, LPR, SC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
-            return fail(KCCOT_EUNSUPPORTED, "sinkhorn_fused: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    // on every launch: the attribute belongs to the current device's copy of the function (a per-process "done" flag
+    // would be wrong on a second device and racy between threads); it is a host-side table write
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sinkhorn_fused_reg<EPT, LPR, SC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+        return fail(KCCOT_EUNSUPPORTED, "sinkhorn_fused: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL((sinkhorn_fused_reg<EPT, LPR, SC>), dim3(3), dim3((a.n * LPR + 63) / 64 * 64), lds, st, a);
     return launch_status("sinkhorn_fused_reg");
 }

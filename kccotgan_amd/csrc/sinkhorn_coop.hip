@@ -8,17 +8,15 @@
 // workgroups of the problem meet at a device-wide barrier, and every lane re-reads the n/64 duals of its
 // columns.  Two barriers per iteration (~2 us each) replace two passes over the matrix.
 //
-// The barrier is a monotonically increasing arrival counter in global memory (one per problem, zeroed by a
-// memset node in front of the launch): thread 0 of a workgroup publishes with an agent-scope release fence and
-// an atomic add, then polls -- with a bounded number of polls: if the workgroups of a problem are not all
-// resident (they are: at most 192 workgroups of 1024 threads on 256 CUs, nothing else on the stream) or
-// anything else goes wrong, the poll gives up, raises an abort flag that every later barrier honours at once,
-// and the kernel drains instead of hanging the device.  Exchange data is read with agent-scope (L1-bypassing)
-// loads after an acquire fence: the workgroups of one problem may sit on different XCDs, each with its own L2.
+// The exchange is flag-in-data (below): every dual travels as one 64-bit {value, half-step tag} word, no counter
+// barrier, no fences.  (Round 1's counter-barrier kernels -- release fence, atomic arrival counter, polling, acquire
+// fence: 0.79 / 0.86 ms per 100 iterations at n = 256 against 0.45 / 0.46 -- and the one-XCD block map were removed
+// in round 3; their A/B records are profiles/r01zo_* and DESIGN.md section 4.)
 #include "common.h"
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include "options.h"
 
 namespace kccot {
 
@@ -33,52 +31,6 @@ struct CoopCtrl {            // per launch, zeroed in front of it
     unsigned bar[32];        // arrival counters, one per problem
     int abort_flag;
     int pad[31];
-};
-
-// Returns false if the solve has been aborted.  `phase` counts this problem's barriers (1, 2, ...).
-__device__ __forceinline__ bool grid_barrier(CoopCtrl* ctrl, int p, unsigned nwg, unsigned phase, int* lds_flag) {
-    __syncthreads();                                   // every wave's stores of this phase are issued
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(&ctrl->bar[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = phase * nwg;
-        unsigned spins = 0;
-        int ab = 0;
-        while (__hip_atomic_load(&ctrl->bar[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            ab = __hip_atomic_load(&ctrl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ab) break;
-            if (++spins > SC_SPIN_LIMIT) {
-                __hip_atomic_store(&ctrl->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ab = 1;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *lds_flag = ab;
-    }
-    __syncthreads();
-    return *lds_flag == 0;
-}
-
-__device__ __forceinline__ float ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-struct SinkCoopArgs {
-    const float* C;
-    int n, L, Lmin, stop_mode;
-    float eps, inv_eps, thresh;
-    float* u_hist;
-    float* v_hist;
-    float* cost_out;
-    int32_t* nits_out;
-    float* pi_out;
-    CoopCtrl* ctrl;
-    float* xu;       // [nprob][n] exchange: current u
-    float* xv;       // [nprob][n]
-    float* errp;     // [nprob][2][SC_MAXWG] per-workgroup sum |du| of the u-update, double-buffered by iteration parity
-    float* costp;    // [nprob][SC_MAXWG]
 };
 
 // one line's dual update: lane holds entries idx = lane + 64 e of its line (c) and of the other side's duals (o)
@@ -103,233 +55,10 @@ __device__ __forceinline__ float coop_update(const float (&c)[EPT], const float 
     return eps * (log_w - lse) + self;
 }
 
-template <int EPT>
-__global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_coop(SinkCoopArgs a) {
-    __shared__ float red[SC_LINES];
-    __shared__ int bflag;
-    const int p = blockIdx.y, wg = blockIdx.x, n = a.n;
-    const unsigned nwg = gridDim.x;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int line = wg * SC_LINES + w;
-    const bool live = line < n;
-    const int lsafe = live ? line : n - 1;
-    const float* C = a.C + (int64_t)p * n * n;
-    float* xu = a.xu + (int64_t)p * n;
-    float* xv = a.xv + (int64_t)p * n;
-    float* errp = a.errp + p * 2 * SC_MAXWG;   // slot it & 1: the next iteration's writers must not race this one's readers
-    const float eps = a.eps, inv_eps = a.inv_eps;
-    const float log_w = logf(1.0f / (float)n);
-
-    float crow[EPT], ccol[EPT], ov[EPT], ou[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = lane + 64 * e;
-        const int ic = idx < n ? idx : n - 1;                     // clamped address, masked in coop_update
-        crow[e] = C[(int64_t)lsafe * n + ic];
-        ccol[e] = C[(int64_t)ic * n + lsafe];
-        ov[e] = 0.f; ou[e] = 0.f;                                  // gan_utils.py:147: u = v = 0
-    }
-    float ui = 0.f, vj = 0.f;
-    unsigned phase = 0;
-    int nits = 0;
-    bool ok = true;
-    for (int it = 0; it < a.L && ok; ++it) {
-        const float un = coop_update<EPT, true>(crow, ov, n, lane, ui, eps, inv_eps, log_w);
-        const float du = live ? fabsf(un - ui) : 0.f;
-        ui = un;
-        if (lane == 0) {
-            red[w] = du;
-            if (live) {
-                xu[line] = un;
-                if (a.u_hist) a.u_hist[((int64_t)p * a.L + it) * n + line] = un;
-            }
-        }
-        __syncthreads();
-        if (t == 0) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < SC_LINES; ++k) s += red[k];
-            errp[(it & 1) * SC_MAXWG + wg] = s;
-        }
-        if (!(ok = grid_barrier(a.ctrl, p, nwg, ++phase, &bflag))) break;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) { const int idx = lane + 64 * e; ou[e] = ld_agent(xu + (idx < n ? idx : n - 1)); }
-        const float vn = coop_update<EPT, false>(ccol, ou, n, lane, vj, eps, inv_eps, log_w);
-        vj = vn;
-        if (lane == 0 && live) {
-            xv[line] = vn;
-            if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + line] = vn;
-        }
-        if (!(ok = grid_barrier(a.ctrl, p, nwg, ++phase, &bflag))) break;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) { const int idx = lane + 64 * e; ov[e] = ld_agent(xv + (idx < n ? idx : n - 1)); }
-        nits = it + 1;
-        // gan_utils.py:157-160 (count-based) / :115-117 (index-based); every workgroup sums the same partials
-        const bool reached = (a.stop_mode == KCCOT_STOP_INDEX) ? (it >= a.Lmin) : (nits >= a.Lmin);
-        if (reached && it + 1 < a.L) {
-            float err = 0.f;
-            for (unsigned k = 0; k < nwg; ++k) err += ld_agent(errp + (it & 1) * SC_MAXWG + k);
-            if (a.thresh > err) break;
-        }
-    }
-    // gan_utils.py:162-164: pi = exp((-C + u + v^T)/eps); cost = sum(pi * C)
-    float part = 0.f;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = lane + 64 * e;
-        if (live && idx < n) {
-            const float pi = __builtin_amdgcn_exp2f(((-crow[e] + ui) + ov[e]) * inv_eps * SC_LOG2E);
-            part += pi * crow[e];
-            if (a.pi_out) a.pi_out[(int64_t)p * n * n + (int64_t)line * n + idx] = pi;
-        }
-    }
-    part = wave_sum_fast(part);
-    if (lane == 0) red[w] = part;
-    __syncthreads();
-    if (t == 0) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < SC_LINES; ++k) s += red[k];
-        a.costp[p * SC_MAXWG + wg] = s;
-    }
-    grid_barrier(a.ctrl, p, nwg, ++phase, &bflag);
-    if (wg == 0 && t == 0) {
-        float s = 0.f;
-        for (unsigned k = 0; k < nwg; ++k) s += ld_agent(a.costp + p * SC_MAXWG + k);
-        a.cost_out[p] = ok ? s : NAN;      // an aborted solve (see grid_barrier) must not look like a result
-        a.nits_out[p] = ok ? nits : -1;    // negative count = aborted (kccot_sinkhorn_status)
-        a.nits_out[gridDim.y + p] = nits;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------
-// reverse sweep (see sinkhorn.hip for the derivation; natural units as in sinkhorn_gen.hip)
-struct SinkCoopBwdArgs {
-    const float* C;
-    const float* u_hist;
-    const float* v_hist;
-    const int32_t* nits;
-    const float* gcost;
-    float* dC;       // [nprob][n][n]: row-layout part
-    float* dCT;      // [nprob][n][n]: column-layout part, transposed (added by add_transposed_batched)
-    int n, L;
-    float eps, inv_eps;
-    CoopCtrl* ctrl;
-    float* xgu;      // [nprob][n]
-    float* xgv;
-};
-
-template <int EPT>
-__global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_coop(SinkCoopBwdArgs a) {
-    __shared__ int bflag;
-    const int p = blockIdx.y, wg = blockIdx.x, n = a.n;
-    const unsigned nwg = gridDim.x;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int line = wg * SC_LINES + w;
-    const bool live = line < n;
-    const int lsafe = live ? line : n - 1;
-    const float* C = a.C + (int64_t)p * n * n;
-    float* xgu = a.xgu + (int64_t)p * n;
-    float* xgv = a.xgv + (int64_t)p * n;
-    const float eps = a.eps, inv_eps = a.inv_eps, g = a.gcost[p];
-    const int nits = a.nits[p];
-    if (nits < 0) {          // aborted forward solve: NaN gradient, every workgroup of the problem leaves before any barrier
-        for (int e = 0; e < EPT; ++e) {
-            const int idx = lane + 64 * e;
-            if (live && idx < n) { a.dC[((int64_t)p * n + line) * n + idx] = NAN; a.dCT[((int64_t)p * n + line) * n + idx] = NAN; }
-        }
-        return;
-    }
-    const float* uh = a.u_hist + (int64_t)p * a.L * n;     // history index k holds (u_{k+1}, v_{k+1}); u_0 = v_0 = 0
-    const float* vh = a.v_hist + (int64_t)p * a.L * n;
-    const float aconst = eps * logf(1.0f / (float)n);
-
-    float crow[EPT], ccol[EPT], drow[EPT], dcol[EPT];
-    int idxc[EPT];
-    bool okc[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = lane + 64 * e;
-        okc[e] = live && idx < n;
-        idxc[e] = idx < n ? idx : n - 1;
-        crow[e] = C[(int64_t)lsafe * n + idxc[e]];
-        ccol[e] = C[(int64_t)idxc[e] * n + lsafe];
-        drow[e] = 0.f; dcol[e] = 0.f;
-    }
-    auto hist = [&](const float* h, int it, int i) { return it >= 1 ? h[(int64_t)(it - 1) * n + i] : 0.f; };
-    // final-cost term: dC = g pi (1 - C/eps); gu = g sum_j pi C / eps; gv likewise
-    float gu_line, gv_line;
-    {
-        const float ui = hist(uh, nits, lsafe), vj = hist(vh, nits, lsafe);
-        float su = 0.f, sv = 0.f;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const float vo = hist(vh, nits, idxc[e]), uo = hist(uh, nits, idxc[e]);
-            const float pr = okc[e] ? __builtin_amdgcn_exp2f(((-crow[e] + ui) + vo) * inv_eps * SC_LOG2E) : 0.f;
-            drow[e] = g * pr * (1.f - crow[e] * inv_eps);
-            su += pr * crow[e];
-            const float pc = okc[e] ? __builtin_amdgcn_exp2f(((-ccol[e] + uo) + vj) * inv_eps * SC_LOG2E) : 0.f;
-            sv += pc * ccol[e];
-        }
-        gu_line = g * wave_sum_fast(su) * inv_eps;
-        gv_line = g * wave_sum_fast(sv) * inv_eps;
-        if (lane == 0 && live) { xgu[line] = gu_line; xgv[line] = gv_line; }
-    }
-    unsigned phase = 0;
-    bool ok = grid_barrier(a.ctrl, p, nwg, ++phase, &bflag);
-    for (int it = nits; it >= 1 && ok; --it) {
-        // (A) row pass with Q_t: gu_i = [it == nits] gu_i - sum_j Q_ij gv_j ; dC_ij += Q_ij gv_j
-        {
-            const float ui = hist(uh, it, lsafe);
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const float vo = hist(vh, it, idxc[e]);
-                const float gvj = ld_agent(xgv + idxc[e]);
-                const float qq = okc[e] ? __builtin_amdgcn_exp2f((((-crow[e] + ui) + vo) - aconst) * inv_eps * SC_LOG2E) : 0.f;
-                const float wv = qq * gvj;
-                drow[e] += wv;
-                s += wv;
-            }
-            s = wave_sum_fast(s);
-            gu_line = (it == nits ? gu_line : 0.f) - s;
-            if (lane == 0 && live) xgu[line] = gu_line;
-        }
-        if (!(ok = grid_barrier(a.ctrl, p, nwg, ++phase, &bflag))) break;
-        // (B) column pass with P_t: gv_j = -sum_i P_ij gu_i ; dC_ij += P_ij gu_i (kept in column layout)
-        {
-            const float vj = hist(vh, it - 1, lsafe);
-            float r = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const float uo = hist(uh, it, idxc[e]);
-                const float gui = ld_agent(xgu + idxc[e]);
-                const float pp = okc[e] ? __builtin_amdgcn_exp2f((((-ccol[e] + uo) + vj) - aconst) * inv_eps * SC_LOG2E) : 0.f;
-                const float wv = pp * gui;
-                dcol[e] += wv;
-                r += wv;
-            }
-            r = wave_sum_fast(r);
-            gv_line = -r;
-            if (lane == 0 && live) xgv[line] = gv_line;
-        }
-        ok = grid_barrier(a.ctrl, p, nwg, ++phase, &bflag);
-    }
-    float* dC = a.dC + (int64_t)p * n * n;
-    float* dCT = a.dCT + (int64_t)p * n * n;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        if (okc[e]) {
-            dC[(int64_t)line * n + idxc[e]] = drow[e];
-            dCT[(int64_t)line * n + idxc[e]] = dcol[e];      // row `line` of dC^T = column `line` of dC
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Flag-in-data exchange ("LL" kernels, the default).
+// Flag-in-data exchange ("LL" kernels).
 //
-// The counter barrier above costs ~3.9 us per half-step at n = 256: a workgroup barrier that drains the store
+// A counter barrier costs ~3.9 us per half-step at n = 256: a workgroup barrier that drains the store
 // queue, an L2 write-back (release), an atomic round trip, polling, an invalidate (acquire) and only then the loads
 // of the new duals.  Here every dual travels as ONE 64-bit word {value, tag}: the tag is the half-step number, the
 // store and the load are relaxed agent-scope atomics (a naturally aligned 64-bit access is single-copy atomic), so
@@ -338,7 +67,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_coop(SinkCoopBwdArgs 
 // releases the other fifteen waves.  A word is overwritten (tag + 2) only by a workgroup that has gathered the whole
 // other side with tag + 1, and those words are published only by workgroups that have gathered this side with
 // `tag`: nobody can lose a value.  The exchange words are zeroed in front of every launch (tags start at 1).
-// Polling is bounded and honours the abort flag exactly as grid_barrier does.
+// Polling is bounded (SC_SPIN_LIMIT) and honours the abort flag of CoopCtrl: a missing workgroup drains the launch.
 // The stop test needs sum_i |u_i - u_i_prev| (gan_utils.py:157): every wave holds all of u (new and previous) across
 // its lanes after the gather, so each wave sums it for itself in the same fixed order -- identical decisions, no
 // exchange.
@@ -395,17 +124,9 @@ struct SinkLLArgs {
     ll_word* xu;      // [nprob][n]
     ll_word* xv;      // [nprob][n]
     ll_word* xcost;   // [nprob][SC_MAXWG]
-    int nwg, nprob, xcd_map;
-    int fault;        // fault injection (KCCOT_SK_FAULT_INJECT=1, tests only): the last workgroup of problem 0 never takes part
+    int nwg, nprob;
+    int fault;        // libkccot_diag.so only (KCCOT_SK_FAULT_INJECT=1): the last workgroup of problem 0 never takes part
 };
-
-// blockIdx -> (problem, workgroup of the problem).  xcd_map: workgroups are dealt round-robin to the 8 XCDs, so
-// problem = id % 8 puts all workgroups of a problem behind ONE L2 (ids with id % 8 >= nprob have nothing to do).
-__device__ __forceinline__ bool ll_role(int xcd_map, int nwg, int nprob, int& p, int& wg) {
-    if (xcd_map) { p = blockIdx.x & 7; wg = blockIdx.x >> 3; return p < nprob && wg < nwg; }
-    p = blockIdx.y; wg = blockIdx.x;
-    return true;
-}
 
 template <int EPT>
 __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
@@ -413,8 +134,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
     __shared__ float shv[SC_MAXWG * SC_LINES];
     __shared__ float red[SC_MAXWG];
     __shared__ int bflag;
-    int p, wg;
-    if (!ll_role(a.xcd_map, a.nwg, a.nprob, p, wg)) return;
+    const int p = blockIdx.y, wg = blockIdx.x;
     if (a.fault && p == 0 && wg == a.nwg - 1) return;      // stands in for a workgroup that is not resident
     const int n = a.n, nwg = a.nwg;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -542,7 +262,7 @@ struct SinkLLBwdArgs {
     CoopCtrl* ctrl;
     ll_word* xgu;
     ll_word* xgv;
-    int nwg, nprob, xcd_map;
+    int nwg, nprob;
 };
 
 template <int EPT>
@@ -550,8 +270,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
     __shared__ float shu[SC_MAXWG * SC_LINES];
     __shared__ float shv[SC_MAXWG * SC_LINES];
     __shared__ int bflag;
-    int p, wg;
-    if (!ll_role(a.xcd_map, a.nwg, a.nprob, p, wg)) return;
+    const int p = blockIdx.y, wg = blockIdx.x;
     const int n = a.n;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int line = wg * SC_LINES + w;
@@ -668,10 +387,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
 size_t sinkhorn_gen_workspace_bytes(int nprob, int n);
 __global__ void add_transposed_batched(const float* __restrict__ in, float* __restrict__ out, int n);
 
-static bool coop_enabled() {
-    const char* e = getenv("KCCOT_SK_NO_COOP");      // =1: the single-workgroup streaming kernels (A/B, fallback)
-    return !(e && atoi(e) == 1);
-}
+static bool coop_enabled() { return opt(OPT_SK_COOP) != 0; }   // option "sinkhorn_coop" = 0: the single-workgroup streaming kernels
 
 // How many 1024-thread workgroups of the cooperative kernels the current device can hold AT ONCE: the spin-wait
 // exchanges are only safe when every workgroup of a launch is resident (a workgroup that has not started cannot
@@ -679,11 +395,11 @@ static bool coop_enabled() {
 // reverse sweep), queried once per device; three quarters of it are offered, so that a co-running kernel (an RCCL
 // collective of the data-parallel trainer, another stream) does not turn a legal launch into a bounded-poll abort.
 // A partitioned / CU-masked / smaller device simply reports fewer CUs and larger batches take the streaming solver.
-// KCCOT_SK_COOP_MAX_WG=<n> overrides the result (tests: force the fallback by capacity).
+// Option "sinkhorn_coop_max_wg" = n > 0 overrides the result (a caller that knows its partition; tests force the fallback).
 static int coop_capacity() {
     static int cached[64];
     static bool have[64];
-    if (const char* e = getenv("KCCOT_SK_COOP_MAX_WG")) return atoi(e);
+    if (const int forced = opt(OPT_SK_COOP_MAX_WG)) return forced;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     if (!have[dev]) {
@@ -694,8 +410,6 @@ static int coop_capacity() {
         m = per_cu < m ? per_cu : m;
         KCCOT_OCC(sinkhorn_fwd_ll<4>) KCCOT_OCC(sinkhorn_fwd_ll<8>) KCCOT_OCC(sinkhorn_fwd_ll<16>)
         KCCOT_OCC(sinkhorn_bwd_ll<4>) KCCOT_OCC(sinkhorn_bwd_ll<8>) KCCOT_OCC(sinkhorn_bwd_ll<16>)
-        KCCOT_OCC(sinkhorn_fwd_coop<4>) KCCOT_OCC(sinkhorn_fwd_coop<8>) KCCOT_OCC(sinkhorn_fwd_coop<16>)
-        KCCOT_OCC(sinkhorn_bwd_coop<4>) KCCOT_OCC(sinkhorn_bwd_coop<8>) KCCOT_OCC(sinkhorn_bwd_coop<16>)
 #undef KCCOT_OCC
         cached[dev] = (int)((long long)cus * m * 3 / 4);
         have[dev] = true;
@@ -708,21 +422,15 @@ bool sinkhorn_coop_eligible(int nprob, int n) {
     return coop_enabled() && n > 128 && n <= 1024 && nprob <= 32 && nwg * nprob <= coop_capacity();   // all workgroups resident
 }
 
+// Fault injection exists in the diagnostic twin only (make libkccot_diag.so; tests/test_gpu_parity.py loads it in a child
+// process): one workgroup of problem 0 stays away, which exercises the bounded-poll abort path.
 static int fault_injected() {
-    const char* e = getenv("KCCOT_SK_FAULT_INJECT");   // tests only: one workgroup of problem 0 stays away (abort path)
+#ifdef KCCOT_DIAG
+    const char* e = getenv("KCCOT_SK_FAULT_INJECT");
     return (e && atoi(e) == 1) ? 1 : 0;
-}
-
-struct CoopCarve { CoopCtrl* ctrl; float* x0; float* x1; float* e0; float* e1; float* second; };
-static CoopCarve coop_carve(void* ws, int nprob, int n) {
-    char* b = static_cast<char*>(ws);
-    CoopCarve c;
-    c.ctrl = reinterpret_cast<CoopCtrl*>(b);
-    float* f = reinterpret_cast<float*>(b + sizeof(CoopCtrl));
-    c.x0 = f; c.x1 = f + (size_t)nprob * n;
-    c.e0 = c.x1 + (size_t)nprob * n; c.e1 = c.e0 + (size_t)nprob * 2 * SC_MAXWG;
-    c.second = reinterpret_cast<float*>(b + sinkhorn_gen_workspace_bytes(nprob, n) / 2);
-    return c;
+#else
+    return 0;
+#endif
 }
 
 // flag-in-data kernels: ctrl | xu [nprob][n] words | xv | xcost [nprob][SC_MAXWG] words, zeroed as one block
@@ -738,82 +446,40 @@ static LLCarve ll_carve(void* ws, int nprob, int n) {
     c.second = reinterpret_cast<float*>(b + sinkhorn_gen_workspace_bytes(nprob, n) / 2);
     return c;
 }
-static bool ll_enabled() {
-    const char* e = getenv("KCCOT_SK_COOP_BARRIER");   // =1: the counter-barrier kernels (A/B)
-    return !(e && atoi(e) == 1);
-}
-// KCCOT_SK_COOP_XCD=1: all workgroups of a problem on one XCD (needs nprob <= 8 and at most one workgroup per CU of
-// an XCD).  Measured SLOWER than the plain grid (n = 256: 5.6 vs 4.5 us per iteration, n = 512: 9.3 vs 5.5) -- the
-// agent-scope words are served by the fabric either way, and one XCD's share of it is the narrower path -- so it is
-// off by default and kept as an experiment knob.
-static bool ll_xcd_map(int nprob, int nwg) {
-    const char* e = getenv("KCCOT_SK_COOP_XCD");
-    return e && atoi(e) == 1 && nprob <= 8 && nwg <= 32;
-}
-
 int launch_sinkhorn_fwd_coop(const float* C, int nprob, int n, float eps, int L, int Lmin, float thresh, int stop_mode,
                              float* u_hist, float* v_hist, float* cost_out, int32_t* nits_out, float* pi_out, void* ws,
                              hipStream_t st) {
-    if (ll_enabled()) {
-        const LLCarve lv = ll_carve(ws, nprob, n);
-        if (lv.zero_bytes > sinkhorn_gen_workspace_bytes(nprob, n) / 2) return fail(KCCOT_EWORKSPACE, "sinkhorn_fwd(coop): exchange area");
-        if (hipMemsetAsync(lv.ctrl, 0, lv.zero_bytes, st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_fwd(coop): memset failed");
-        const int nwg = (n + SC_LINES - 1) / SC_LINES;
-        const int xm = ll_xcd_map(nprob, nwg) ? 1 : 0;
-        SinkLLArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
-                     lv.ctrl, lv.x0, lv.x1, lv.xc, nwg, nprob, xm, fault_injected()};
-        const dim3 grid = xm ? dim3(8 * nwg) : dim3(nwg, nprob);
-        const int ept = (n + 63) / 64;
-#define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_fwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)
-        if (ept <= 4) KCCOT_LL(4); else if (ept <= 8) KCCOT_LL(8); else KCCOT_LL(16);
-#undef KCCOT_LL
-        return launch_status("sinkhorn_fwd_ll");
-    }
-    const CoopCarve cv = coop_carve(ws, nprob, n);
-    if (hipMemsetAsync(cv.ctrl, 0, sizeof(CoopCtrl), st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_fwd(coop): memset failed");
-    SinkCoopArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
-                   cv.ctrl, cv.x0, cv.x1, cv.e0, cv.e1};
-    const dim3 grid((n + SC_LINES - 1) / SC_LINES, nprob);
+    const LLCarve lv = ll_carve(ws, nprob, n);
+    if (lv.zero_bytes > sinkhorn_gen_workspace_bytes(nprob, n) / 2) return fail(KCCOT_EWORKSPACE, "sinkhorn_fwd(coop): exchange area");
+    if (hipMemsetAsync(lv.ctrl, 0, lv.zero_bytes, st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_fwd(coop): memset failed");
+    const int nwg = (n + SC_LINES - 1) / SC_LINES;
+    SinkLLArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
+                 lv.ctrl, lv.x0, lv.x1, lv.xc, nwg, nprob, fault_injected()};
+    const dim3 grid(nwg, nprob);
     const int ept = (n + 63) / 64;
-#define KCCOT_COOP(E) hipLaunchKernelGGL(sinkhorn_fwd_coop<E>, grid, dim3(SC_THREADS), 0, st, a)
-    if (ept <= 4) KCCOT_COOP(4); else if (ept <= 8) KCCOT_COOP(8); else KCCOT_COOP(16);
-#undef KCCOT_COOP
-    return launch_status("sinkhorn_fwd_coop");
+#define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_fwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)
+    if (ept <= 4) KCCOT_LL(4); else if (ept <= 8) KCCOT_LL(8); else KCCOT_LL(16);
+#undef KCCOT_LL
+    return launch_status("sinkhorn_fwd_ll");
 }
 
 int launch_sinkhorn_bwd_coop(const float* C, const float* u_hist, const float* v_hist, const int32_t* nits, int nprob, int n,
                              float eps, int L, const float* gcost, float* dC, void* ws, hipStream_t st) {
-    if (ll_enabled()) {
-        const LLCarve lv = ll_carve(ws, nprob, n);
-        if (lv.zero_bytes > sinkhorn_gen_workspace_bytes(nprob, n) / 2) return fail(KCCOT_EWORKSPACE, "sinkhorn_bwd(coop): exchange area");
-        if (hipMemsetAsync(lv.ctrl, 0, lv.zero_bytes, st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_bwd(coop): memset failed");
-        const int nwg = (n + SC_LINES - 1) / SC_LINES;
-        const int xm = ll_xcd_map(nprob, nwg) ? 1 : 0;
-        SinkLLBwdArgs a{C, u_hist, v_hist, nits, gcost, dC, lv.second, n, L, eps, (float)(1.0 / (double)eps), lv.ctrl, lv.x0, lv.x1,
-                        nwg, nprob, xm};
-        const dim3 grid = xm ? dim3(8 * nwg) : dim3(nwg, nprob);
-        const int ept = (n + 63) / 64;
-#define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_bwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)
-        if (ept <= 4) KCCOT_LL(4); else if (ept <= 8) KCCOT_LL(8); else KCCOT_LL(16);
-#undef KCCOT_LL
-        int rc = launch_status("sinkhorn_bwd_ll");
-        if (rc) return rc;
-        dim3 tg((n + 31) / 32, (n + 31) / 32, nprob);
-        hipLaunchKernelGGL(add_transposed_batched, tg, dim3(256), 0, st, (const float*)lv.second, dC, n);
-        return launch_status("add_transposed_batched");
-    }
-    const CoopCarve cv = coop_carve(ws, nprob, n);
-    if (hipMemsetAsync(cv.ctrl, 0, sizeof(CoopCtrl), st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_bwd(coop): memset failed");
-    SinkCoopBwdArgs a{C, u_hist, v_hist, nits, gcost, dC, cv.second, n, L, eps, (float)(1.0 / (double)eps), cv.ctrl, cv.x0, cv.x1};
-    const dim3 grid((n + SC_LINES - 1) / SC_LINES, nprob);
+    const LLCarve lv = ll_carve(ws, nprob, n);
+    if (lv.zero_bytes > sinkhorn_gen_workspace_bytes(nprob, n) / 2) return fail(KCCOT_EWORKSPACE, "sinkhorn_bwd(coop): exchange area");
+    if (hipMemsetAsync(lv.ctrl, 0, lv.zero_bytes, st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_bwd(coop): memset failed");
+    const int nwg = (n + SC_LINES - 1) / SC_LINES;
+    SinkLLBwdArgs a{C, u_hist, v_hist, nits, gcost, dC, lv.second, n, L, eps, (float)(1.0 / (double)eps), lv.ctrl, lv.x0, lv.x1,
+                    nwg, nprob};
+    const dim3 grid(nwg, nprob);
     const int ept = (n + 63) / 64;
-#define KCCOT_COOP(E) hipLaunchKernelGGL(sinkhorn_bwd_coop<E>, grid, dim3(SC_THREADS), 0, st, a)
-    if (ept <= 4) KCCOT_COOP(4); else if (ept <= 8) KCCOT_COOP(8); else KCCOT_COOP(16);
-#undef KCCOT_COOP
-    int rc = launch_status("sinkhorn_bwd_coop");
+#define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_bwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)
+    if (ept <= 4) KCCOT_LL(4); else if (ept <= 8) KCCOT_LL(8); else KCCOT_LL(16);
+#undef KCCOT_LL
+    int rc = launch_status("sinkhorn_bwd_ll");
     if (rc) return rc;
     dim3 tg((n + 31) / 32, (n + 31) / 32, nprob);
-    hipLaunchKernelGGL(add_transposed_batched, tg, dim3(256), 0, st, (const float*)cv.second, dC, n);
+    hipLaunchKernelGGL(add_transposed_batched, tg, dim3(256), 0, st, (const float*)lv.second, dC, n);
     return launch_status("add_transposed_batched");
 }
 

@@ -500,13 +500,10 @@ int launch_sinkhorn_fwd_gen(const float* C, int nprob, int n, float eps, int L, 
     int rc = launch_status("transpose_batched");
     if (rc) return rc;
     SinkGenArgs a{C, CT, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out};
-    const bool wide = (n % 4 == 0) && ((uintptr_t)C % 16 == 0) && !getenv("KCCOT_SK_GEN_NARROW");
-    const bool sixteen = !getenv("KCCOT_SK_GEN_WAVE_LINES");   // =1: one line per wave instruction (A/B)
+    const bool wide = (n % 4 == 0) && ((uintptr_t)C % 16 == 0);
     if (!wide) hipLaunchKernelGGL(sinkhorn_fwd_gen, dim3(nprob), dim3(SG_THREADS), 0, st, a);
-    else if (n <= 256 && sixteen) hipLaunchKernelGGL(sinkhorn_fwd_gen16<4>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
-    else if (n <= 512 && sixteen) hipLaunchKernelGGL(sinkhorn_fwd_gen16<8>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
-    else if (n <= 256) hipLaunchKernelGGL(sinkhorn_fwd_gen4<1>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
-    else if (n <= 512) hipLaunchKernelGGL(sinkhorn_fwd_gen4<2>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
+    else if (n <= 256) hipLaunchKernelGGL(sinkhorn_fwd_gen16<4>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
+    else if (n <= 512) hipLaunchKernelGGL(sinkhorn_fwd_gen16<8>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
     else hipLaunchKernelGGL(sinkhorn_fwd_gen4<4>, dim3(nprob), dim3(SG_THREADS), 0, st, a);
     return launch_status("sinkhorn_fwd_gen");
 }

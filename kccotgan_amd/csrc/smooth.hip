@@ -10,6 +10,7 @@
 // This is the first, pass-per-axis version: HBM traffic is one read + one write of the tensor
 // per axis plus the max/scale pass (algorithmic minimum: one read + one write in total).
 #include "common.h"
+#include "options.h"
 #include <math.h>
 #include <float.h>
 #include <stdlib.h>
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(NT) void smooth_plane(PlaneArgs a) {
 // Adjoint weights: w_k(p) = w[k] + [p >= 1] w[-2p-k] + [p <= L-2] w[2(L-1)-2p-k] (taps outside -R..R
 // are zero), sources outside [0,L) do not exist; the head fold is known at compile time, the tail
 // fold depends on d = L-1-p and is chosen with scalar selects.
-enum { WALK_MAX = 0, WALK_WRITE = 1, WALK_RAW = 2, WALK_ADJ = 3, WALK_ADJX = 4, WALK_COOP = 5, WALK_RAW_TW = 6 };
+enum { WALK_MAX = 0, WALK_WRITE = 1, WALK_RAW = 2, WALK_ADJ = 3, WALK_ADJX = 4, WALK_RAW_TW = 6 };
 
 // WALK_RAW_TW (C == 1, four consecutive w per thread, W/4 a power of two <= 64): the T walk with the W stencil of
 // smooth_w1 applied to every T-smoothed piece before it is stored -- the left / right neighbour pieces of a row are the
@@ -360,18 +361,9 @@ __device__ __forceinline__ float from_next_lane(float v) {   // lane i <- lane i
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
-// WALK_COOP: WALK_MAX and WALK_WRITE in ONE launch, for tensors that fit the register files of the device (one line of
-// the axis per thread, all workgroups resident): every thread keeps its smoothed line in registers, the workgroups
-// publish their maxima and meet at a device-wide barrier, every workgroup reduces the (few hundred) maxima itself and
-// writes s / max.  The tensor is read ONCE and written once -- the algorithmic minimum -- where the two-pass form
-// evaluates the stencil twice (second read from the Infinity Cache) behind three launches.  Same arithmetic in the same
-// order as WALK_MAX / WALK_WRITE, and max is exact and order-independent: bit-identical results.
-// The barrier is the cooperative Sinkhorn's (sinkhorn_coop.hip): arrival counter zeroed in front of the launch, agent-
-// scope release / acquire, BOUNDED polling -- if the workgroups were not all resident (the host checks occupancy x CUs
-// before choosing this mode) the poll gives up and the launch writes NaN, never a plausible number.
-struct WalkCtrl { unsigned bar; int abort_flag; };
-constexpr unsigned WALK_SPIN_LIMIT = 1u << 20;
-
+// (A cooperative single-launch form of the last stage -- lines kept in registers across a device-wide barrier, tensor read
+// once and written once -- was built in round 2, measured SLOWER than the two passes (22.7 + 4.6 us against 8.3 + 12.5 us
+// at configs[1], profiles/r03a_prof_smooth_coop_vs_two_pass.txt) and removed in round 3.)
 struct WalkArgs {
     const float* in;       // forward: input; adjoint: incoming gradient
     const float* out_fwd;  // WALK_ADJX: the forward's normalised output
@@ -379,8 +371,7 @@ struct WalkArgs {
     float* blockmax;       // WALK_MAX
     const float* mx;       // WALK_WRITE / WALK_ADJX: device scalar, the tensor maximum
     const float* res;      // WALK_ADJX: {sum gout*out, #ties}
-    WalkCtrl* ctrl;        // WALK_COOP: barrier words (zeroed in front of the launch)
-    float* mx_out;         // WALK_COOP, WALK_WRITE with nblk > 0: the tensor maximum is written here
+    float* mx_out;         // WALK_WRITE with nblk > 0: the tensor maximum is written here
     int nblk;              // WALK_WRITE: > 0 = reduce blockmax[0, nblk) (the preceding WALK_MAX launch's) instead of reading mx
     int L;                 // axis length
     int64_t S;             // axis stride in floats
@@ -401,7 +392,6 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
     typedef typename WalkVec<VW>::type V;
     constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX;
     __shared__ float red[16];
-    __shared__ int coop_flag;
     const int L = a.L;
     const int64_t S = a.S;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -441,7 +431,6 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
         else win[j] = (j < R) ? zero : ((j - R < L) ? x[j - R] : zero);    // nothing before 0 / after L-1
     }
     float vmax = -FLT_MAX;
-    V y[MODE == WALK_COOP ? LMAX : 1];  // WALK_COOP: the smoothed line stays in registers across the device-wide barrier
 #pragma unroll
     for (int p = 0; p < LMAX; ++p) {
         const bool live = p < L;        // uniform
@@ -489,12 +478,11 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
                 vat<VW>(acc, j) = o;
             }
         }
-        if (MODE == WALK_MAX || MODE == WALK_COOP) {
+        if (MODE == WALK_MAX) {
             float mx = vat<VW>(acc, 0);
 #pragma unroll
             for (int c = 1; c < VW; ++c) mx = fmaxf(mx, vat<VW>(acc, c));
             vmax = live ? fmaxf(vmax, mx) : vmax;
-            if (MODE == WALK_COOP) y[MODE == WALK_COOP ? p : 0] = acc;
         } else {
             if (MODE == WALK_WRITE) {
 #pragma unroll
@@ -521,42 +509,6 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
     if (MODE == WALK_MAX && a.blockmax) {
         const float bm = block_max(ok ? vmax : -FLT_MAX, red);
         if (threadIdx.x == 0) a.blockmax[blockIdx.x] = bm;
-    }
-    if (MODE == WALK_COOP) {
-        const float bm = block_max(ok ? vmax : -FLT_MAX, red);
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(&a.blockmax[blockIdx.x], bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(&a.ctrl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            int ab = 0;
-            while (__hip_atomic_load(&a.ctrl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-                ab = __hip_atomic_load(&a.ctrl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ab) break;
-                if (++spins > WALK_SPIN_LIMIT) {
-                    __hip_atomic_store(&a.ctrl->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ab = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            coop_flag = ab;
-        }
-        __syncthreads();
-        float mall = -FLT_MAX;
-        for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
-            mall = fmaxf(mall, __hip_atomic_load(&a.blockmax[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        mall = block_max(mall, red);
-        if (coop_flag) mall = NAN;                       // aborted barrier: not a result
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.mx_out[0] = mall;
-#pragma unroll
-        for (int p = 0; p < LMAX; ++p) {
-            V o = y[MODE == WALK_COOP ? p : 0];
-#pragma unroll
-            for (int c = 0; c < VW; ++c) vat<VW>(o, c) = vat<VW>(o, c) / mall;
-            if (ok && p < L) *reinterpret_cast<V*>(a.out + off + (int64_t)p * S) = o;
-        }
     }
 }
 
@@ -939,10 +891,10 @@ static size_t tw_plane_lds(int T, int W, int C, int radius, bool adjoint) {
 }
 
 static bool tw_plane_eligible(int T, int W, int C, int radius, bool adjoint, const void* p0, const void* p1) {
-    if (const char* e = getenv("KCCOT_SMOOTH_NO_TWPLANE")) if (atoi(e) == 1) return false;
-    // the adjoint form is opt-in (KCCOT_SMOOTH_TWPLANE_BWD=1): its border-weight table reads make it SLOWER than the
-    // separate W^T and T^T stages (configs[3] shape: 741 vs 682 us for the whole 3-D adjoint); forward: 456 vs 545 us
-    if (adjoint) { const char* e = getenv("KCCOT_SMOOTH_TWPLANE_BWD"); if (!(e && atoi(e) == 1)) return false; }
+    if (!opt(OPT_SMOOTH_FUSED_TW)) return false;
+    // forward only: the adjoint form's border-weight table reads made it SLOWER than the separate W^T and T^T stages
+    // (configs[3] shape: 741 vs 682 us for the whole 3-D adjoint; forward: 456 vs 545 us)
+    if (adjoint) return false;
     return (radius == 3 || radius == 4) && C >= 1 && C <= 4 && ((W * C) & 3) == 0 && T > radius && W > radius &&
            (((uintptr_t)p0 | (uintptr_t)p1) & 15) == 0 && tw_plane_lds(T, W, C, radius, adjoint) <= 156 * 1024;
 }
@@ -1029,7 +981,6 @@ static WalkPlan walk_plan(int L, int64_t S, bool two_inputs, const void* p0, con
     pl.lmax = L <= 32 ? 32 : 64;
     // registers: LMAX x VW floats for the line (twice that in flight while two tensors are being read)
     int vw = (pl.lmax == 32) ? (two_inputs ? 2 : 4) : (two_inputs ? 1 : 2);
-    if (const char* e = getenv("KCCOT_SMOOTH_VW")) { const int v = atoi(e); if ((v == 1 || v == 2) && v < vw) vw = v; }   // tuning knob
     while (vw > 1 && (S % vw != 0 || (uintptr_t)p0 % (4 * vw) || (uintptr_t)p1 % (4 * vw) || (uintptr_t)p2 % (4 * vw))) vw >>= 1;
     pl.vw = vw;
     return pl;
@@ -1054,7 +1005,6 @@ static int launch_walk(int mode, WalkArgs wa, int radius, int64_t numel, WalkPla
         case WALK_WRITE: KCCOT_WALK_MODE(WALK_WRITE); break;
         case WALK_RAW: KCCOT_WALK_MODE(WALK_RAW); break;
         case WALK_ADJ: KCCOT_WALK_MODE(WALK_ADJ); break;
-        case WALK_COOP: KCCOT_WALK_MODE(WALK_COOP); break;
         case WALK_RAW_TW: KCCOT_WALK_MODE(WALK_RAW_TW); break;
         default: KCCOT_WALK_MODE(WALK_ADJX); break;
     }
@@ -1092,10 +1042,7 @@ static int launch_roll(int mode, WalkArgs wa, int radius, int64_t numel, int vw,
 // AXIS_NONE = neither (radius other than 3 / 4, or an adjoint weight table that does not fit LDS): the caller falls back to
 // the per-element chain.  KCCOT_SMOOTH_GENERIC=1 takes the rolling form wherever it exists (tests, A/B).
 enum { AXIS_NONE = 0, AXIS_LINE = 1, AXIS_ROLL = 2 };
-static bool smooth_generic() {
-    const char* e = getenv("KCCOT_SMOOTH_GENERIC");
-    return e && atoi(e) == 1;
-}
+static bool smooth_generic() { return opt(OPT_SMOOTH_GENERIC) != 0; }   // option "smooth_generic" = 1: the any-shape kernels everywhere
 struct AxisPlan { int kind; WalkPlan wp; int vw; };
 
 static AxisPlan axis_plan(int L, int64_t S, bool two_inputs, bool adjoint, int radius, const void* p0, const void* p1,
@@ -1114,48 +1061,6 @@ static AxisPlan axis_plan(int L, int64_t S, bool two_inputs, bool adjoint, int r
 static int launch_axis(int mode, const WalkArgs& wa, int radius, int64_t numel, const AxisPlan& ap, hipStream_t st) {
     if (ap.kind == AXIS_LINE) return launch_walk(mode, wa, radius, numel, ap.wp, st);
     return launch_roll(mode, wa, radius, numel, ap.vw, st);
-}
-
-// How many 256-thread workgroups of the WALK_COOP instantiation (radius, plan) the device holds at once: CU count x
-// occupancy, three quarters of it offered (a co-running kernel must not turn a legal launch into a bounded-poll abort);
-// KCCOT_SMOOTH_COOP_MAX_WG=<n> overrides (tests: force the two-pass form by capacity), KCCOT_SMOOTH_NO_COOP=1 disables.
-template <int R>
-static int walk_coop_occupancy(WalkPlan pl) {
-    int per_cu = 0;
-    hipError_t e;
-    if (pl.lmax == 32) {
-        if (pl.vw == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_walk<R, 32, 4, WALK_COOP>, 256, 0);
-        else if (pl.vw == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_walk<R, 32, 2, WALK_COOP>, 256, 0);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_walk<R, 32, 1, WALK_COOP>, 256, 0);
-    } else {
-        if (pl.vw == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_walk<R, 64, 2, WALK_COOP>, 256, 0);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_walk<R, 64, 1, WALK_COOP>, 256, 0);
-    }
-    return e == hipSuccess ? per_cu : 0;
-}
-
-// opt-in (KCCOT_SMOOTH_COOP=1): measured at configs[1] the single launch is SLOWER than the two passes (22.7 us + 4.6 us
-// for zeroing its barrier word against 8.3 + 12.5 us): its phases -- load, stencil, barrier (two memory-side round
-// trips), divide, store -- run one after the other on every CU at once, where the passes overlap them across waves.
-static bool walk_coop_wanted() {
-    const char* e = getenv("KCCOT_SMOOTH_COOP");
-    return e && atoi(e) == 1;
-}
-
-static bool walk_coop_fits(int radius, WalkPlan pl, int64_t nwg) {
-    if (const char* e = getenv("KCCOT_SMOOTH_COOP_MAX_WG")) return nwg <= atoi(e);
-    static int cached[64][2][2][3];      // [device][radius 3/4][lmax 32/64][vw 1/2/4]
-    static bool have[64][2][2][3];
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    const int ri = radius == 3 ? 0 : 1, li = pl.lmax == 32 ? 0 : 1, vi = pl.vw == 4 ? 2 : (pl.vw == 2 ? 1 : 0);
-    if (!have[dev][ri][li][vi]) {
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-        const int occ = radius == 3 ? walk_coop_occupancy<3>(pl) : walk_coop_occupancy<4>(pl);
-        cached[dev][ri][li][vi] = (int)((long long)cus * occ * 3 / 4);
-        have[dev][ri][li][vi] = true;
-    }
-    return nwg <= cached[dev][ri][li][vi];
 }
 
 // sum(gout * out) and #(out == 1) with wide grid-stride loads (the per-element form above launches
@@ -1180,7 +1085,6 @@ static bool plane_eligible(int T, int W, int C, int radius, int naxes) {
 }
 
 static int plane_hseg(int B, int H, bool halo) {
-    if (const char* e = getenv("KCCOT_SMOOTH_HSEG")) { const int v = atoi(e); if (v >= 1) return v; }   // tuning knob
     // >= 2 workgroups per CU; with an H stencil each segment re-reads 2R halo planes, so segments
     // stay as long as that allows
     for (int hs = halo ? 16 : 8; hs > 2; hs >>= 1)
@@ -1267,14 +1171,14 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
     // division by the all-reduced one -- must evaluate s with the SAME kernels, or the arg-max element comes out as
     // 0.99999994 instead of exactly 1 and the adjoint's `out == 1` tie detection finds nothing: found by the RCCL
     // world-size-1 test, where phase 1 took the per-axis chain and phase 2 the streamed walks)
-    if (r34 && !getenv("KCCOT_SMOOTH_NO_STREAM") && (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W))) {
+    if (r34 && opt(OPT_SMOOTH_STREAM) && (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W))) {
         const int64_t WC = (int64_t)W * C;
         const bool three = axes != KCCOT_SMOOTH_T;
         // the last stage runs twice (maxima, then recompute + write s / max); earlier stages write raw sums
         AxisPlan pt = axis_plan(T, WC, false, false, radius, in, out, three ? tmp : out);
         // temporal-only call: 8-byte pieces (twice the threads) are 4-6 % faster than 16-byte ones on both passes at every
         // BASELINE shape (22.2 -> 20.8 us, 101 -> 97 us, 227 -> 216 us); the 3-D call keeps 16-byte pieces for the T+W fusion
-        if (!three && pt.kind == AXIS_LINE && pt.wp.vw == 4 && !getenv("KCCOT_SMOOTH_VW")) { pt.wp.vw = 2; pt.vw = 2; }
+        if (!three && pt.kind == AXIS_LINE && pt.wp.vw == 4) { pt.wp.vw = 2; pt.vw = 2; }
         const AxisPlan ph = three ? axis_plan(H, (int64_t)T * WC, false, false, radius, tmp, out, out) : AxisPlan{AXIS_LINE, WalkPlan{1, 32}, 1};
         const bool w1 = three && w1_eligible(W, C, radius, out, tmp) && !smooth_generic();
         const bool wplane = three && !w1 && plane_eligible(T, W, C, radius, 1) && !smooth_generic();
@@ -1289,7 +1193,7 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
                 // T: in -> out (raw);  W: out -> tmp (raw; the axis is contiguous: smooth_w1 / LDS rows);  H: tmp -> out
                 // -- or T and W in one launch, in -> tmp (WALK_RAW_TW), when a row of W is W/4 lanes of a wave
                 const int W4 = W >> 2;
-                const bool tw = w1 && pt.kind == AXIS_LINE && pt.vw == 4 && W4 <= 64 && (W4 & (W4 - 1)) == 0 && !getenv("KCCOT_SMOOTH_NO_TW");
+                const bool tw = w1 && pt.kind == AXIS_LINE && pt.vw == 4 && W4 <= 64 && (W4 & (W4 - 1)) == 0 && opt(OPT_SMOOTH_FUSED_TW);
                 // -- or, for any channel count, with the (b, h) plane staged in LDS (smooth_tw_plane)
                 const bool twp = !tw && tw_plane_eligible(T, W, C, radius, false, in, tmp);
                 if (twp) {
@@ -1316,14 +1220,6 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
             }
             wa.in = last_in;
             const int64_t last_wgs = (n / wa.L / last.vw + 255) / 256;
-            if (!ext && !nodiv && last.kind == AXIS_LINE && walk_coop_wanted() && walk_coop_fits(radius, last.wp, last_wgs)) {
-                // maxima + division in one launch, the smoothed lines held in registers across a device-wide barrier
-                WalkCtrl* ctrl = reinterpret_cast<WalkCtrl*>(one + 16);
-                if (hipMemsetAsync(ctrl, 0, sizeof(WalkCtrl), st) != hipSuccess)
-                    return fail(KCCOT_EINVAL, "smooth_fwd: memset failed");
-                wa.out = out; wa.blockmax = bmax; wa.ctrl = ctrl; wa.mx_out = max_inout;
-                return launch_walk(WALK_COOP, wa, radius, n, last.wp, st);
-            }
             wa.nblk = 0;
             if (!ext) {
                 wa.out = nullptr; wa.blockmax = bmax;
@@ -1421,7 +1317,7 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
     }
     float* scal = reinterpret_cast<float*>(p + 2 * align_up((size_t)nb * sizeof(float), 256));   // workspace scalars {.., .., .., .., 1, 0, 0}
     const unsigned axes = flags & (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W);
-    if ((radius == 3 || radius == 4) && !getenv("KCCOT_SMOOTH_NO_STREAM") &&
+    if ((radius == 3 || radius == 4) && opt(OPT_SMOOTH_STREAM) &&
         (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W))) {
         const int64_t WC = (int64_t)W * C;
         const bool three = axes != KCCOT_SMOOTH_T;
@@ -1461,15 +1357,6 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
             wa.in = tmp; wa.out = din; wa.L = T; wa.S = WC;
             return launch_axis(WALK_ADJ, wa, radius, n, pt, st);
         }
-    }
-    // The fused adjoint (smooth_plane<R,true>) is correct but measured slower than the per-axis
-    // chain at the configs[1] shape (r01: 3-D fwd+bwd 524 us vs 402 us); opt-in until it is tuned.
-    if (plane_eligible(T, W, C, radius, na) && getenv("KCCOT_SMOOTH_FUSED_BWD")) {
-        PlaneArgs pa{};
-        pa.in = gout; pa.out_fwd = out; pa.out = din; pa.mx = max_in; pa.res = res;
-        pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C; pa.axes = axes; pa.tp = tp;
-        pa.hseg = plane_hseg(B, H, (flags & KCCOT_SMOOTH_H) != 0);
-        return launch_plane(pa, radius, true, dim3((H + pa.hseg - 1) / pa.hseg, B), st);
     }
     hipLaunchKernelGGL(maxnorm_bwd_apply, dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, max_in, (const float*)res, ds);
     if ((rc = launch_status("maxnorm_bwd_apply"))) return rc;

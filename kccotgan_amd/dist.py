@@ -25,6 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from . import gan_utils
 from ._lib import lib, check, ptr, stream_of, workspace
 
 _THRESH = 10 ** (-2)
@@ -248,6 +249,7 @@ class _KSplitLoss(torch.autograd.Function):
               "pairwise_cost3(from gram sums)")
         loss, saved = HipOps.divergence_fwd(C3, eps, L)
         last_info["nits"], last_info["nits_executed"] = saved[3][:3], saved[3][3:]
+        gan_utils.last_info["compute_sinkhorn_loss"] = saved[3][:3]      # raise_if_solver_aborted() covers the sharded loss too
         ctx.saved_state = (saved, real_s, fake_s, h_fake, h_real, m_real, m_fake)
         ctx.cfg = (sc, rank * Bl, Bl, group)
         return loss
@@ -341,6 +343,7 @@ class _ShardedLoss(torch.autograd.Function):
             loss = (2.0 * cost3[0] - cost3[1]) - cost3[2]       # gan_utils.py:225
         if ops is HipOps:
             last_info["nits"], last_info["nits_executed"] = saved[3][:3], saved[3][3:]
+            gan_utils.last_info["compute_sinkhorn_loss"] = saved[3][:3]  # raise_if_solver_aborted() covers the sharded loss too
         ctx.saved_state = (saved, real, fake, h_fake, h_real, m_real, m_fake)
         ctx.cfg = (sc, rank * Bl, Bl, ops)
         return loss

@@ -39,6 +39,13 @@ _NATIVE_DEFAULT = "" if MIOPEN_WORKAROUND_GUARANTEED else "convlstm,deconv,dconv
 _NATIVE = set(filter(None, os.environ.get("KCCOT_NATIVE_CONV", _NATIVE_DEFAULT).split(",")))
 
 
+def convolution_mode():
+    """Which kernels the G/D convolutions run on: 'miopen' (the fast default), or 'native:<families>' when layer families
+    were moved to the ATen kernels (KCCOT_NATIVE_CONV, or the import-order fallback kccotgan_amd/__init__.py warns about).
+    Reported by KCCOTTrainer.convolution_mode, tools/bench_train.py and bench.py's train_steps_per_sec block."""
+    return "native:" + ",".join(sorted(_NATIVE)) if _NATIVE else "miopen"
+
+
 def _backend(kind):
     return torch.backends.cudnn.flags(enabled=False) if kind in _NATIVE else contextlib.nullcontext()
 

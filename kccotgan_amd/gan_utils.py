@@ -440,13 +440,16 @@ def compute_sinkhorn_loss(f_real, f_fake, scaling_coef, sinkhorn_eps, sinkhorn_l
                                float(scaling_coef), eps, L, _LMIN, "compute_sinkhorn_loss")
 
 
-def raise_if_solver_aborted():
-    """Synchronising status check of the most recent solves (``kccot_sinkhorn_status``): raises ``KccotError`` if a
-    multi-CU Sinkhorn solve gave up (negative iteration count; its cost and gradients are NaN).  The training loop
-    calls it where the reference has its non-finite-loss guard (kernel_train.py:323), so that an aborted solve is
-    reported as what it is and not as an exploded loss."""
-    for tag in ("compute_sinkhorn_loss", "compute_sinkhorn", "benchmark_sinkhorn"):
-        nits = last_info.get(tag)
+def raise_if_solver_aborted(tags=("compute_sinkhorn_loss",)):
+    """Synchronising status check of the solves recorded under ``tags`` in ``last_info`` (``kccot_sinkhorn_status``): raises
+    ``KccotError`` if a multi-CU Sinkhorn solve gave up (negative iteration count; its cost and gradients are NaN).  The
+    training loop calls it where the reference has its non-finite-loss guard (kernel_train.py:323), so that an aborted
+    solve is reported as what it is and not as an exploded loss.  Default: the loss the trainer just evaluated (the
+    single-GPU and the batch-sharded path both record their counts under "compute_sinkhorn_loss"); pass
+    ``("compute_sinkhorn",)`` / ``("benchmark_sinkhorn",)`` after a direct call of those.  A checked entry is dropped, so a
+    stale record of an earlier call can never be blamed for a later NaN."""
+    for tag in tags:
+        nits = last_info.pop(tag, None)
         if nits is None or not torch.is_tensor(nits) or not nits.is_cuda:
             continue
         nits = nits.contiguous()

@@ -98,6 +98,7 @@ class KCCOTTrainer:
         self.scaling_coef = 1.0 / scaling_coef                                  # kernel_train.py:71
         self.sinkhorn_eps, self.sinkhorn_l, self.reg_penalty = sinkhorn_eps, sinkhorn_l, reg_penalty
         self.kernel_choice = kernel
+        self.convolution_mode = gan.convolution_mode()      # 'miopen' or 'native:...' (the slow fallback; see gan.py)
         data_parallel = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         # :216; data-parallel: the division is by the maximum of the GLOBAL batch, as in the single-process run
         self.gaussian_kernel = KernelSmoothing(temporal_kernel_size=6, spatial_kernel_size=6, group=group, sharded=data_parallel)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_lib.lib, s), "libkccot.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
-    assert _lib.lib.kccot_version() == 201
+    assert _lib.lib.kccot_version() == 300
 
 
 def test_argument_validation_happens_before_any_launch():
@@ -114,3 +114,34 @@ def test_no_cpu_fallback():
             if f.endswith((".py", ".hip", ".h")):
                 src += open(os.path.join(root, f)).read()
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_option_table_is_the_only_run_time_switchboard():
+    """kccot_set_option / kccot_get_option: every option the header documents exists with the documented default, unknown
+    names and out-of-range values are rejected, and no entry point reads the environment (the sources contain one getenv:
+    KCCOT_OPTIONS, read once at first use; the fault-injection hook's is compiled into the diagnostic twin only)."""
+    from kccotgan_amd import _lib
+    text = open(os.path.join(ROOT, "include", "kccot.h")).read()
+    documented = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"^ \*   ([a-z0-9_]+)\s+(-?\d+)\s{2,}\S", text, flags=re.M))
+    names = _lib.option_names()
+    assert sorted(documented) == sorted(names), (sorted(documented), sorted(names))
+    for k in names:
+        assert _lib.get_option(k) == documented[k], k           # the CPU tier runs on defaults
+    assert _lib.lib.kccot_set_option(b"no_such_option", 1) == _lib.EINVAL and b"unknown" in _lib.lib.kccot_last_error()
+    assert _lib.lib.kccot_set_option(b"gram_f32", 2) == _lib.EINVAL and b"outside" in _lib.lib.kccot_last_error()
+    assert _lib.lib.kccot_set_option(None, 1) == _lib.EINVAL
+    assert _lib.lib.kccot_option_name(-1) is None and _lib.lib.kccot_option_name(len(names)) is None
+    with _lib.options(sinkhorn_shortcut=0, sinkhorn_fused_max_n=128):
+        assert _lib.get_option("sinkhorn_shortcut") == 0 and _lib.get_option("sinkhorn_fused_max_n") == 128
+        assert _lib.lib.kccot_sinkhorn_fused_eligible(128, 20) == 1
+        with _lib.options(sinkhorn_fused=0):
+            assert _lib.lib.kccot_sinkhorn_fused_eligible(64, 100) == 0
+    assert _lib.get_option("sinkhorn_shortcut") == 1 and _lib.lib.kccot_sinkhorn_fused_eligible(128, 20) == 0
+    src = os.path.join(ROOT, "kccotgan_amd", "csrc")
+    hits = []
+    for fn in sorted(os.listdir(src)):
+        if fn.endswith((".hip", ".h")):
+            body = open(os.path.join(src, fn)).read()
+            body = re.sub(r"#ifdef KCCOT_DIAG.*?#e(?:lse|ndif)", "", body, flags=re.S)
+            hits += [(fn, m.group(0)) for m in re.finditer(r'getenv\("[A-Z_]+"\)', body)]
+    assert hits == [("api.hip", 'getenv("KCCOT_OPTIONS")')], hits

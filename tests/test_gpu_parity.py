@@ -78,7 +78,7 @@ def flat(v):
 
 
 # "mfma" = the default MFMA kernels (bf16 exact-split for full stacks, f32-input otherwise);
-# "mfma_f32" forces the f32-input MFMA kernel everywhere (KCCOT_GRAM_F32=1)
+# "mfma_f32" forces the f32-input MFMA kernel everywhere (option "gram_f32" = 1)
 PATHS = ["auto", "direct", "mfma", "mfma_f32"]
 
 
@@ -87,7 +87,7 @@ def set_path(G, L, path, K=None):
     'tiny' golden shape (K = 24) is below that and only runs the direct kernel."""
     if path.startswith("mfma") and K is not None and (K % 4 != 0 or K < 32):
         pytest.skip("MFMA path not eligible for K=%d" % K)
-    os.environ["KCCOT_GRAM_F32"] = "1" if path == "mfma_f32" else "0"
+    L.set_option("gram_f32", 1 if path == "mfma_f32" else 0)
     G.cost_flags = {"auto": 0, "direct": L.COST_FORCE_DIRECT, "mfma": L.COST_FORCE_MFMA,
                     "mfma_f32": L.COST_FORCE_MFMA}[path]
 
@@ -98,10 +98,13 @@ def kdim(shape):
 
 
 @pytest.fixture(autouse=True)
-def _reset_flags(G):
+def _reset_flags(G, L):
+    """Every test starts and ends on the library's default options (kccot_set_option is process-wide)."""
+    defaults = {k: L.get_option(k) for k in L.option_names()}
     yield
     G.cost_flags = 0
-    os.environ["KCCOT_GRAM_F32"] = "0"
+    for k, v in defaults.items():
+        L.set_option(k, v)
 
 
 # ---------------------------------------------------------------- cost matrices
@@ -237,9 +240,7 @@ def _raw_sinkhorn(L, C, eps, Lc, Lmin, mode, shortcut):
     """kccot_sinkhorn_fwd_f32 + _bwd_f32 through the C ABI; every output, for bitwise comparison."""
     lib, ptr = L.lib, L.ptr
     nprob, n, _ = C.shape
-    old = os.environ.get("KCCOT_SK_NO_SHORTCUT")
-    os.environ["KCCOT_SK_NO_SHORTCUT"] = "0" if shortcut else "1"
-    try:
+    with L.options(sinkhorn_shortcut=1 if shortcut else 0):
         uh = torch.full((nprob, Lc, n), float("nan"), device=DEV)
         vh = torch.full((nprob, Lc, n), float("nan"), device=DEV)
         cost = torch.empty(nprob, device=DEV)
@@ -254,11 +255,6 @@ def _raw_sinkhorn(L, C, eps, Lc, Lmin, mode, shortcut):
         assert lib.kccot_sinkhorn_bwd_f32(ptr(C), ptr(uh), ptr(vh), ptr(nits), nprob, n, eps, Lc, ptr(gc), ptr(dC),
                                           ptr(ws), wsb, None) == 0
         torch.cuda.synchronize()
-    finally:
-        if old is None:
-            del os.environ["KCCOT_SK_NO_SHORTCUT"]
-        else:
-            os.environ["KCCOT_SK_NO_SHORTCUT"] = old
     nit = nits.cpu().numpy()
     out = dict(cost=cost.cpu().numpy(), pi=pi.cpu().numpy(), dC=dC.cpu().numpy(), nits=nit[:nprob], executed=nit[nprob:])
     # only the executed-or-filled part of the history is defined: rows [0, nits)
@@ -275,7 +271,7 @@ def _same_bits(a, b):
 def test_sinkhorn_periodic_state_shortcut_is_bit_exact(G, L):
     """The forward skips iterations once the fp32 state (u, v) repeats bit for bit with period <= 4
     (sinkhorn.hip).  It claims to be EXACT: every output -- cost, plan, iteration count, the full dual history, dC -- must be
-    bit-identical to a run that executes every iteration (KCCOT_SK_NO_SHORTCUT=1)."""
+    bit-identical to a run that executes every iteration (option "sinkhorn_shortcut" = 0)."""
     probs = {}
     for name, (shape, seed, regime) in dict(near=("cfg2", 0, "near"), far=("cfg2", 1, "far"), small=SMALL[0]).items():
         g, inp, t = load(shape, seed, regime)
@@ -307,40 +303,26 @@ def test_sinkhorn_periodic_state_shortcut_is_bit_exact(G, L):
     assert skipped_somewhere      # the test must exercise the jump, not only the fall-through
 
 
-_SOLVER_ENV = {"coop": {}, "coop_barrier": {"KCCOT_SK_COOP_BARRIER": "1"}, "coop_xcd": {"KCCOT_SK_COOP_XCD": "1"},
-               "stream": {"KCCOT_SK_NO_COOP": "1"}}
-
-
-def _solver_env(solver):
-    for k in ("KCCOT_SK_COOP_BARRIER", "KCCOT_SK_COOP_XCD", "KCCOT_SK_NO_COOP"):
-        os.environ.pop(k, None)
-    os.environ.update(_SOLVER_ENV[solver])
-
-
-@pytest.mark.parametrize("solver", ["coop", "coop_barrier", "coop_xcd", "stream"])
+@pytest.mark.parametrize("solver", ["coop", "stream"])
 def test_sinkhorn_large_n_streaming_path(G, L, solver):
-    """n > 128 (BASELINE configs 3-5 batch sizes): the multi-CU cooperative solver (default: flag-in-data exchange;
-    KCCOT_SK_COOP_BARRIER=1: counter barrier; KCCOT_SK_COOP_XCD=1: one XCD per problem) and the single-workgroup
-    streaming kernels it falls back to (KCCOT_SK_NO_COOP=1), forward and reverse sweep, against the oracle / fp64
-    autograd on random cost matrices."""
-    _solver_env(solver)
-    try:
-        for n, Lc, eps in ((130, 25, 0.7), (256, 40, 1.0), (512, 12, 0.5), (1000, 5, 1.0)):
-            Cn = (np.random.default_rng(n).random((2, n, n), dtype=np.float32) * 6).astype(np.float32)
-            C = torch.from_numpy(Cn).to(DEV).requires_grad_(True)
-            cost = G._Sinkhorn.apply(C, eps, Lc, 100, L.STOP_COUNT, "large")
-            w = torch.tensor([1.0, -0.5], device=DEV)
-            (cost * w).sum().backward()
-            assert G.last_info["large"].tolist() == [Lc, Lc]
-            for p in range(2):
-                Cd = torch.from_numpy(Cn[p]).double().requires_grad_(True)
-                ref, nits = ot.sinkhorn_from_cost(Cd, eps, Lc)
-                ref.backward()
-                assert rel(cost[p], ref) < 2e-5, (n, p)
-                gref = Cd.grad.numpy() * float(w[p])
-                np.testing.assert_allclose(C.grad[p].cpu().numpy(), gref, rtol=0, atol=2e-4 * np.abs(gref).max())
-    finally:
-        _solver_env("coop")
+    """n > 128 (BASELINE configs 3-5 batch sizes): the multi-CU solver (flag-in-data exchange) and the single-workgroup
+    streaming kernels it falls back to (option "sinkhorn_coop" = 0), forward and reverse sweep, against the oracle /
+    fp64 autograd on random cost matrices."""
+    L.set_option("sinkhorn_coop", 1 if solver == "coop" else 0)
+    for n, Lc, eps in ((130, 25, 0.7), (256, 40, 1.0), (512, 12, 0.5), (1000, 5, 1.0)):
+        Cn = (np.random.default_rng(n).random((2, n, n), dtype=np.float32) * 6).astype(np.float32)
+        C = torch.from_numpy(Cn).to(DEV).requires_grad_(True)
+        cost = G._Sinkhorn.apply(C, eps, Lc, 100, L.STOP_COUNT, "large")
+        w = torch.tensor([1.0, -0.5], device=DEV)
+        (cost * w).sum().backward()
+        assert G.last_info["large"].tolist() == [Lc, Lc]
+        for p in range(2):
+            Cd = torch.from_numpy(Cn[p]).double().requires_grad_(True)
+            ref, nits = ot.sinkhorn_from_cost(Cd, eps, Lc)
+            ref.backward()
+            assert rel(cost[p], ref) < 2e-5, (n, p)
+            gref = Cd.grad.numpy() * float(w[p])
+            np.testing.assert_allclose(C.grad[p].cpu().numpy(), gref, rtol=0, atol=2e-4 * np.abs(gref).max())
 
 
 def test_sinkhorn_cooperative_stop_rule_and_many_problems(G, L):
@@ -352,37 +334,32 @@ def test_sinkhorn_cooperative_stop_rule_and_many_problems(G, L):
     Cn = (rng.random((3, n, n), dtype=np.float32) * 3).astype(np.float32)
     C = torch.from_numpy(Cn).to(DEV)
     res = {}
-    for solver in ("coop", "coop_barrier", "stream"):
-        _solver_env(solver)
-        try:
+    for solver in ("coop", "stream"):
+        with L.options(sinkhorn_coop=1 if solver == "coop" else 0):
             cost = G._Sinkhorn.apply(C, 1.0, 400, 100, L.STOP_COUNT, "stop")
             res[solver] = (cost.cpu().numpy(), G.last_info["stop"].tolist())
-        finally:
-            _solver_env("coop")
-    assert res["coop"][1] == res["stream"][1] == res["coop_barrier"][1] and res["coop"][1][0] < 400
+    assert res["coop"][1] == res["stream"][1] and res["coop"][1][0] < 400
     np.testing.assert_allclose(res["coop"][0], res["stream"][0], rtol=2e-5)
-    assert np.array_equal(res["coop"][0], res["coop_barrier"][0])      # same arithmetic, only the exchange differs
     many = torch.from_numpy((rng.random((24, n, n), dtype=np.float32) * 3).astype(np.float32)).to(DEV)   # 24 x 10 workgroups > 192
     cost = G._Sinkhorn.apply(many, 1.0, 30, 100, L.STOP_COUNT, "many")
     ref = [o.sinkhorn_from_cost(many[p].cpu().numpy(), 1.0, 30)[0] for p in (0, 23)]
     assert rel(cost[0], ref[0]) < 2e-5 and rel(cost[23], ref[1]) < 2e-5
 
 
-def test_sinkhorn_falls_back_when_the_device_cannot_hold_the_cooperative_grid(G, L, monkeypatch):
+def test_sinkhorn_falls_back_when_the_device_cannot_hold_the_cooperative_grid(G, L):
     """The multi-CU solver is launched only if CU count x occupancy (queried at run time) covers its grid.
-    KCCOT_SK_COOP_MAX_WG stands in for a small / partitioned / CU-masked device: the same call then runs the
+    Option "sinkhorn_coop_max_wg" stands in for a small / partitioned / CU-masked device: the same call then runs the
     one-workgroup streaming solver and returns the same costs, iteration counts and gradients."""
     n = 256
     Cn = (np.random.default_rng(5).random((3, n, n), dtype=np.float32) * 4).astype(np.float32)
     out = {}
     for cap in (None, "8"):
-        if cap:
-            monkeypatch.setenv("KCCOT_SK_COOP_MAX_WG", cap)       # 3 problems x 16 workgroups = 48 > 8
+        L.set_option("sinkhorn_coop_max_wg", int(cap) if cap else 0)   # 3 problems x 16 workgroups = 48 > 8
         C = torch.from_numpy(Cn).to(DEV).requires_grad_(True)
         cost = G._Sinkhorn.apply(C, 1.0, 30, 100, L.STOP_COUNT, "cap")
         cost.sum().backward()
         out[cap] = (cost.detach().cpu().numpy(), G.last_info["cap"].tolist(), C.grad.cpu().numpy())
-    monkeypatch.delenv("KCCOT_SK_COOP_MAX_WG")
+    L.set_option("sinkhorn_coop_max_wg", 0)
     assert out[None][1] == out["8"][1] == [30, 30, 30]
     np.testing.assert_allclose(out["8"][0], out[None][0], rtol=2e-5)
     np.testing.assert_allclose(out["8"][2], out[None][2], rtol=0, atol=2e-4 * np.abs(out[None][2]).max())
@@ -390,33 +367,23 @@ def test_sinkhorn_falls_back_when_the_device_cannot_hold_the_cooperative_grid(G,
     assert rel(out["8"][0][1], ref) < 2e-5
 
 
-def test_sinkhorn_abort_is_nan_plus_status_never_a_plausible_number(G, L, monkeypatch):
-    """Fault injection (KCCOT_SK_FAULT_INJECT=1: one workgroup of problem 0 never takes part -- what a non-resident
-    workgroup looks like to its siblings).  The bounded polling must drain the launch (about a second), and the
-    result must be unmistakable: cost NaN, a NEGATIVE iteration count, kccot_sinkhorn_status = KCCOT_EABORTED,
-    NaN gradients from the reverse sweep, KccotError from the wrapper's status check.  The problem next to it in the
-    same launch and the next launch are unaffected."""
-    from kccotgan_amd._lib import lib, ptr, KccotError, EABORTED
-    n = 256
-    Cn = (np.random.default_rng(6).random((2, n, n), dtype=np.float32) * 4).astype(np.float32)
-    monkeypatch.setenv("KCCOT_SK_FAULT_INJECT", "1")
-    C = torch.from_numpy(Cn).to(DEV).requires_grad_(True)
-    cost = G._Sinkhorn.apply(C, 1.0, 20, 100, L.STOP_COUNT, "compute_sinkhorn")
-    cost.sum().backward()
-    torch.cuda.synchronize()
-    nits = G.last_info["compute_sinkhorn"]
-    assert bool(torch.isnan(cost[0])) and int(nits[0]) < 0
-    assert bool(torch.isnan(C.grad[0]).all())
-    assert lib.kccot_sinkhorn_status(ptr(nits.contiguous()), 2, None) == EABORTED
-    with pytest.raises(KccotError, match="aborted"):
-        G.raise_if_solver_aborted()
-    monkeypatch.delenv("KCCOT_SK_FAULT_INJECT")
-    C2 = torch.from_numpy(Cn).to(DEV)
-    cost2 = G._Sinkhorn.apply(C2, 1.0, 20, 100, L.STOP_COUNT, "compute_sinkhorn")
-    ref = [o.sinkhorn_from_cost(Cn[p], 1.0, 20)[0] for p in range(2)]
-    assert rel(cost2[0], ref[0]) < 2e-5 and rel(cost2[1], ref[1]) < 2e-5
-    assert G.last_info["compute_sinkhorn"].tolist() == [20, 20]
-    G.raise_if_solver_aborted()            # clean again
+def test_sinkhorn_abort_is_nan_plus_status_never_a_plausible_number():
+    """Fault injection (one workgroup of problem 0 never takes part -- what a non-resident workgroup looks like to its
+    siblings).  The hook exists in the diagnostic twin of the library only (make libkccot_diag.so, -DKCCOT_DIAG), so the
+    scenario runs in a child process that loads that build: tests/sk_abort_child.py holds the assertions (cost NaN, a
+    NEGATIVE iteration count, kccot_sinkhorn_status = KCCOT_EABORTED, NaN gradients, KccotError from the wrapper; the
+    problem next to it in the same launch and the next launch unaffected)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "kccotgan_amd", "csrc", "libkccot_diag.so")
+    if not os.path.exists(diag):
+        pytest.skip("libkccot_diag.so is not built (python -c 'import __graft_entry__ as g; g.build()' builds it)")
+    env = dict(os.environ, KCCOT_LIB_PATH=diag, KCCOT_SK_FAULT_INJECT="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "sk_abort_child.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "abort path ok" in r.stdout
 
 
 @pytest.mark.parametrize("B,regime", [(128, "near"), (192, "far"), (256, "near")])
@@ -454,70 +421,87 @@ def test_cost3_blocked_mfma_path_above_64(G, L, B, regime):
         np.testing.assert_allclose(np.diag(blocked[k]), np.diag(ref), rtol=2e-5, atol=1e-7, err_msg=tag + " diagonal")
 
 
-@pytest.mark.parametrize("B", [128, 256, 384])
-def test_tiled_gram_presplit_planes_equal_the_in_kernel_split(G, B, monkeypatch):
-    """KCCOT_GRAM_PRESPLIT=1 (opt-in: measured slower) cuts the stack [real ; fake - real] ONCE
-    into its three exact bf16 planes (presplit_stack) and the tiled Gram's producers copy from them; the default keeps
-    the split inside the kernel.  Same pieces, same MFMAs in the same order: the three cost matrices are bit-identical."""
-    rng = np.random.default_rng(2000 + B)
-    K, T, J = 2560, 10, 8
+def _tile_inputs(B, K, seed, T=10, J=8):
+    rng = np.random.default_rng(seed)
     real = torch.from_numpy(rng.random((B, K), dtype=np.float32)).to(DEV)
     fake = torch.from_numpy(np.clip(real.cpu().numpy() + 0.05 * rng.standard_normal((B, K)).astype(np.float32), 0, 1)).to(DEV)
-    f = [torch.from_numpy(rng.random((B, T, J), dtype=np.float32)).to(DEV) for _ in range(4)]
+    f = [torch.from_numpy(rng.random((B, T, J), dtype=np.float32)).to(DEV) for _ in range(4)]    # h_fake, h_real, m_real, m_fake
+    return real, fake, f
+
+
+def _cost3_oracle(real, fake, f):
+    x, y = real.cpu().numpy().astype(np.float64), fake.cpu().numpy().astype(np.float64)
+    fn = [t.cpu().numpy() for t in f]
+    out = []
+    for a, b, h, M, pairdiff in ((x, y, fn[0], fn[2], True), (x, x, fn[1], fn[2], False), (y, y, fn[0], fn[3], False)):
+        l2 = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2 * a @ b.T
+        n = np.arange(a.shape[0])
+        l2[n, n] = ((a - b) ** 2).sum(1) if pairdiff else 0.0
+        out.append(l2 * cases.SC + o.causal_term(h, M, cases.SC, dtype=np.float64))
+    return out
+
+
+@pytest.mark.parametrize("B,K", [(256, 2560), (256, 2560 + 36), (512, 3072 + 4), (768, 1536)])
+def test_tile256_gram_against_the_128_row_tiles_the_direct_kernel_and_the_oracle(G, L, B, K):
+    """B % 256 == 0: the 256-row pair tiles (cost_tile256.hip: E written by the (X_i, E_i) pairs, triangular tile map on
+    diagonal pairs, one K-chunk per partial tile) against the 128-row tiles they replace (option "cost_tile256" = 0), the
+    direct-difference kernel and the fp64 oracle -- K a multiple of 32, K % 32 != 0 (the RAGGED instantiation: last granule
+    partial), a single chunk, six panels."""
+    real, fake, f = _tile_inputs(B, K, 2000 + B + K)
     out = {}
-    for mode in ("planes", "inkernel"):
-        if mode == "planes":
-            monkeypatch.setenv("KCCOT_GRAM_PRESPLIT", "1")
-        else:
-            monkeypatch.delenv("KCCOT_GRAM_PRESPLIT")
-        out[mode] = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
-    assert _same_bits(out["planes"], out["inkernel"])
-    ref = o.modified_cost(real.cpu().numpy()[:, None, :], fake.cpu().numpy()[:, None, :], f[0].cpu().numpy(), f[2].cpu().numpy(),
-                          cases.SC, np.float64)
-    np.testing.assert_allclose(out["planes"][0], ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+    out["t256"] = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
+    with L.options(cost_tile256=0):
+        out["t128"] = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
+    G.cost_flags = L.COST_FORCE_DIRECT
+    out["direct"] = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
+    G.cost_flags = 0
+    ref = _cost3_oracle(real, fake, f)
+    for k, tag in enumerate(("xy", "xx", "yy")):
+        tol = 1e-5 * np.abs(ref[k]).max()
+        for name in ("t256", "t128", "direct"):
+            np.testing.assert_allclose(out[name][k], ref[k], rtol=0, atol=tol, err_msg="%s %s" % (name, tag))
+        np.testing.assert_allclose(np.diag(out["t256"][k]), np.diag(ref[k]), rtol=2e-5, atol=1e-7, err_msg=tag + " diagonal")
+    assert np.all(np.diag(out["t256"][1]) == np.diag(out["direct"][1]))          # x == y: exactly the causal term
+    # symmetric distances of the x == y problems: bitwise mirror images (one Gram entry serves both)
+    caus = [o.causal_term(f[1].cpu().numpy(), f[2].cpu().numpy(), cases.SC, dtype=np.float64),
+            o.causal_term(f[0].cpu().numpy(), f[3].cpu().numpy(), cases.SC, dtype=np.float64)]
+    for k in (1, 2):
+        d = out["t256"][k].astype(np.float64) - caus[k - 1]
+        np.testing.assert_allclose(d, d.T, rtol=0, atol=2e-6 * np.abs(d).max())
 
 
-@pytest.mark.parametrize("B", [128, 256, 384])
-def test_tiled_gram_with_materialised_difference_rows_equals_subtracting_while_staging(G, B, monkeypatch):
-    """Large batches (default B >= 512; KCCOT_GRAM_EDIFF_MINB) form E = fake - real ONCE in fp32 (ediff_rows) and the tiled
-    Gram's E panels stream that buffer instead of subtracting two row streams every time a panel is staged.  Same
-    subtraction, same split, same MFMAs: the three cost matrices are bit-identical either way."""
-    rng = np.random.default_rng(3000 + B)
-    K, T, J = 2560 + 36, 10, 8
-    real = torch.from_numpy(rng.random((B, K), dtype=np.float32)).to(DEV)
-    fake = torch.from_numpy(np.clip(real.cpu().numpy() + 0.05 * rng.standard_normal((B, K)).astype(np.float32), 0, 1)).to(DEV)
-    f = [torch.from_numpy(rng.random((B, T, J), dtype=np.float32)).to(DEV) for _ in range(4)]
-    out = {}
-    for mode, minb in (("ediff", "128"), ("staging", "0")):
-        monkeypatch.setenv("KCCOT_GRAM_EDIFF_MINB", minb)
-        out[mode] = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
-    assert np.isfinite(out["ediff"]).all()
-    assert _same_bits(out["ediff"], out["staging"])
+def test_tiled_gram_128_row_tiles_with_materialised_difference_rows(G, L):
+    """B = 640 (a multiple of 128 that is not one of 256, >= 512): the 128-row tiles with E = fake - real formed once
+    (ediff_rows), ten panels, against the fp64 oracle."""
+    B, K = 640, 2560 + 36
+    real, fake, f = _tile_inputs(B, K, 3640)
+    got = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
+    ref = _cost3_oracle(real, fake, f)
+    for k, tag in enumerate(("xy", "xx", "yy")):
+        np.testing.assert_allclose(got[k], ref[k], rtol=0, atol=1e-5 * np.abs(ref[k]).max(), err_msg=tag)
+        np.testing.assert_allclose(np.diag(got[k]), np.diag(ref[k]), rtol=2e-5, atol=1e-7, err_msg=tag + " diagonal")
 
 
-@pytest.mark.parametrize("B,K", [(64, 122880), (64, 4100), (37, 3076), (7, 256), (64, 64 * 300 + 36), (33, 128)])
-def test_gram_two_stage_producers_equal_the_one_stage_form(G, B, K, monkeypatch):
-    """The default producers of gram128_partial_x3ws keep two stages of UNCONDITIONAL (clamped) loads in flight and zero
-    the out-of-range values with selects; KCCOT_GRAM_DEEP=0 is the one-stage form with predicated loads.  Same values into
-    the same MFMAs in the same order: bit-identical cost matrices, including ragged row blocks (B < 64), K-chunks that
-    end inside a stage, chunks of one or two stages and K that is no multiple of the stage."""
-    rng = np.random.default_rng(77 + B + K)
-    T, J = 6, 4
-    real = torch.from_numpy(rng.random((B, K), dtype=np.float32)).to(DEV)
-    fake = (real + 0.02 * torch.randn(B, K, device=DEV)).clamp_(0, 1).contiguous()
-    f = [torch.from_numpy(rng.random((B, T, J), dtype=np.float32)).to(DEV) for _ in range(4)]
-    out = {}
-    for mode in ("deep", "shallow"):
-        if mode == "shallow":
-            monkeypatch.setenv("KCCOT_GRAM_DEEP", "0")
-        else:
-            monkeypatch.delenv("KCCOT_GRAM_DEEP", raising=False)
-        out[mode] = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
-    assert np.isfinite(out["deep"]).all()
-    assert _same_bits(out["deep"], out["shallow"])
+@pytest.mark.parametrize("B,K", [(64, 4100), (37, 3076), (7, 256), (64, 64 * 300 + 36), (33, 128)])
+def test_gram_producers_on_ragged_shapes(G, L, B, K):
+    """The producers of gram128_partial_x3ws keep two stages of UNCONDITIONAL (clamped) loads in flight and zero the
+    out-of-range values with selects: ragged row blocks (B < 64), K-chunks that end inside a stage, chunks of one or two
+    stages and K that is no multiple of the stage, against the direct-difference kernel and the fp64 oracle."""
+    real, fake, f = _tile_inputs(B, K, 77 + B + K, T=6, J=4)
+    G.cost_flags = L.COST_FORCE_MFMA
+    got = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
+    G.cost_flags = L.COST_FORCE_DIRECT
+    direct = G._Cost3.apply(real, fake, f[0], f[1], f[2], f[3], cases.SC).cpu().numpy()
+    G.cost_flags = 0
+    ref = _cost3_oracle(real, fake, f)
+    assert np.isfinite(got).all()
+    for k in range(3):
+        tol = 1e-5 * np.abs(ref[k]).max()
+        np.testing.assert_allclose(got[k], ref[k], rtol=0, atol=tol)
+        np.testing.assert_allclose(direct[k], ref[k], rtol=0, atol=tol)
 
 
-@pytest.mark.parametrize("B", [48, 64, 128])
+@pytest.mark.parametrize("B", [48, 64, 128, 256])
 def test_cost3_gram_sums_split_equals_one_call(L, B):
     """KCCOT_COST_GRAM_SUMS_ONLY + KCCOT_COST_FROM_GRAM_SUMS (the contraction-sharded caller's two calls, here without
     the all-reduce in between) give the bits of the one-shot call; and summing the Gram sums of two K-halves before
@@ -857,25 +841,21 @@ def test_smoothing_gradient_matches_autograd(shape, ksize):
         np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.numpy(), rtol=0, atol=2e-4 * float(a.grad.abs().max()))
 
 
-def test_smoothing_stream_and_legacy_paths_agree():
+def test_smoothing_stream_and_legacy_paths_agree(L):
     """The streamed kernels (register walks along T / H, register W kernel) against the per-axis chain
-    they replace (KCCOT_SMOOTH_NO_STREAM=1): forward and gradient, at a shape that takes every fast path."""
+    they replace (option "smooth_stream" = 0): forward and gradient, at a shape that takes every fast path."""
     from kccotgan_amd.data_utils import KernelSmoothing
     ks = KernelSmoothing(6, 6)
     v = torch.rand((3, 40, 30, 64, 1), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
     wgt = torch.randn(v.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
     res = {}
     for mode in ("stream", "legacy"):
-        if mode == "legacy":
-            os.environ["KCCOT_SMOOTH_NO_STREAM"] = "1"
-        try:
+        with L.options(smooth_stream=0 if mode == "legacy" else 1):
             for name, fn in (("t", ks.temporal_convolution), ("3d", ks.gaussian_convolution3D)):
                 x = v.clone().requires_grad_(True)
                 y = fn(x, 3.0)
                 (g,) = torch.autograd.grad(y, x, wgt)
                 res[mode, name] = (y.detach().cpu().numpy(), g.cpu().numpy())
-        finally:
-            os.environ.pop("KCCOT_SMOOTH_NO_STREAM", None)
     for name in ("t", "3d"):
         np.testing.assert_allclose(res["stream", name][0], res["legacy", name][0], rtol=2e-6, atol=1e-7)
         gs, gl = res["stream", name][1], res["legacy", name][1]
@@ -924,12 +904,12 @@ def test_rbf_mmd_gradient_wrt_fake():
 
 
 # ---------------------------------------------------------------- one-call loss and graph capture
-def test_one_call_loss_equals_staged_path(G, L, monkeypatch):
+def test_one_call_loss_equals_staged_path(G, L):
     """The one-call loss entry points (cost assembly + fused solve/sweep, or the two-kernel sequence where the history
     does not fit LDS) against _Cost3 followed by _SinkhornDivergence: bit-identical values and gradients.  (The
     staged reverse sweep is pinned to the fused kernel's 8 lanes per line for 32 < n <= 64, where it defaults to 16:
     another summation order of the same terms otherwise.)"""
-    monkeypatch.setenv("KCCOT_SK_LPR", "8")
+    L.set_option("sinkhorn_lanes_per_line", 8)
     for shape, seed, regime in (SMALL[0], ("cfg2", 1, "far")):
         g, inp, t = load(shape, seed, regime)
         wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]
@@ -988,16 +968,16 @@ def test_graphed_loss_is_bit_identical(G, L):
 @pytest.mark.parametrize("shortcut", ["on", "off"])
 @pytest.mark.parametrize("shape,seed,regime", [("tiny", 0, "near"), ("small", 1, "far"), ("cfg1", 1, "far"), ("deci64", 0, "near"),
                                                ("cfg2", 0, "near"), ("cfg2", 1, "far")])
-def test_fused_solve_and_sweep_equals_the_two_kernel_path(G, shape, seed, regime, shortcut, monkeypatch):
+def test_fused_solve_and_sweep_equals_the_two_kernel_path(G, L, shape, seed, regime, shortcut):
     """compute_sinkhorn_loss with a gradient runs the three solves AND the reverse sweep as one persistent launch
-    with the dual history in LDS (sinkhorn_fused_reg) wherever that history fits; KCCOT_SK_NO_FUSED=1 restores the
+    with the dual history in LDS (sinkhorn_fused_reg) wherever that history fits; option "sinkhorn_fused" = 0 restores the
     forward kernel + global history + sweep kernel.  Same arithmetic instruction for instruction: loss, costs and
     iteration counts are bit-identical, and so are all gradients when the two-kernel sweep runs at the same
-    lanes-per-line (KCCOT_SK_LPR=8 for 32 < n <= 64, where it otherwise uses 16).  A non-unit upstream gradient rides
+    lanes-per-line (option "sinkhorn_lanes_per_line" = 8 for 32 < n <= 64, where it otherwise uses 16).  A non-unit upstream gradient rides
     on scaling_coef in the fused form (one extra rounding)."""
     g, inp, _ = load(shape, seed, regime)
     if shortcut == "off":
-        monkeypatch.setenv("KCCOT_SK_NO_SHORTCUT", "1")
+        L.set_option("sinkhorn_shortcut", 0)
     wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]
 
     def run(upstream):
@@ -1011,8 +991,8 @@ def test_fused_solve_and_sweep_equals_the_two_kernel_path(G, shape, seed, regime
                 [a.cpu().numpy() for a in grads])
 
     fused = {u: run(u) for u in (1.0, -0.37)}
-    monkeypatch.setenv("KCCOT_SK_NO_FUSED", "1")
-    monkeypatch.setenv("KCCOT_SK_LPR", "8")
+    L.set_option("sinkhorn_fused", 0)
+    L.set_option("sinkhorn_lanes_per_line", 8)
     plain = {u: run(u) for u in (1.0, -0.37)}
     assert fused[1.0][3] and not plain[1.0][3]
     assert _same_bits(fused[1.0][0].reshape(1), plain[1.0][0].reshape(1)) and fused[1.0][1] == plain[1.0][1]
@@ -1029,7 +1009,7 @@ def test_fused_solve_and_sweep_equals_the_two_kernel_path(G, shape, seed, regime
 
 
 @pytest.mark.parametrize("Lc", [0, 1, 3, 101, 130])
-def test_fused_path_at_degenerate_and_late_stopping_iteration_counts(G, Lc, monkeypatch):
+def test_fused_path_at_degenerate_and_late_stopping_iteration_counts(G, L, Lc):
     """L = 0 (no iteration: plan exp(-C/eps), gan_utils.py:151 never enters the loop), 1, 3, and L > Lmin = 100 where the
     stop rule may fire (quirk 2): fused launch == two-kernel path bit for bit, both == the fp64 oracle."""
     g, inp, _ = load("small", 1, "far")
@@ -1046,7 +1026,7 @@ def test_fused_path_at_degenerate_and_late_stopping_iteration_counts(G, Lc, monk
 
     fused = run()
     assert bool(G.last_info["compute_sinkhorn_loss_fused_sweep"])
-    monkeypatch.setenv("KCCOT_SK_NO_FUSED", "1")
+    L.set_option("sinkhorn_fused", 0)
     plain = run()
     assert _same_bits(fused[0], plain[0]) and fused[1] == plain[1]
     for a, b in zip(fused[2], plain[2]):
@@ -1159,32 +1139,29 @@ def test_full_size_configs_3_and_4_against_the_oracle(G, shape, Lc):
         assert abs(float(rbf_mmd2(real, real.clone()))) <= 1e-6
 
 
-@pytest.mark.parametrize("form", ["0", "1"])
-def test_large_batch_video_gradient_forms_agree(G, form, monkeypatch):
-    """B = 256: the one-launch 256-row-tile video gradient in its 64-column (KCCOT_APPLY_M256_N64=1) and 128-column
-    (=0) forms against the 64-row block form (KCCOT_APPLY_NO_M256=1): same exact split, same products, another tiling
-    of the stack -- equal to fp32 summation order (1e-6 of max|grad|)."""
-    B, H, T, W, C = 256, 8, 10, 8, 5          # K = 3200: 25 column tiles of 128, the last one partial for 64 / full for 128
+def test_large_batch_video_gradient_forms_agree(G, L):
+    """B = 256: the one-launch 256-row-tile video gradient (apply_coeffs_x3_m256; its 128-column form takes over at
+    K >= 655 360 and is checked against the fp64 formula at configs[4] in tests/test_gpu_fullsize_grads.py) against the
+    64-row block form (option "apply_m256" = 0): same exact split, same products, another tiling of the stack -- equal to
+    fp32 summation order (1e-6 of max|grad|)."""
+    B, H, T, W, C = 256, 8, 10, 8, 5          # K = 3200: 50 column tiles of 64
     gen = torch.Generator(device=DEV).manual_seed(4242)
     real = torch.rand((B, H, T, W, C), device=DEV, generator=gen)
     fake = (real + 0.05 * torch.randn(real.shape, device=DEV, generator=gen)).clamp_(0, 1)
     f = {k: torch.rand((B, T, 8), device=DEV, generator=gen) for k in ("h_fake", "m_real", "h_real", "m_fake")}
     grads = {}
     for mode in ("tile", "block"):
-        if mode == "tile":
-            monkeypatch.setenv("KCCOT_APPLY_M256_N64", form)
-        else:
-            monkeypatch.setenv("KCCOT_APPLY_NO_M256", "1")
-        fk = fake.clone().requires_grad_(True)
-        loss = G.compute_sinkhorn_loss(real, fk, cases.SC, 0.8, 100, f["h_fake"], f["m_real"], f["h_real"], f["m_fake"])
-        (grads[mode],) = torch.autograd.grad(loss, fk)
+        with L.options(apply_m256=1 if mode == "tile" else 0):
+            fk = fake.clone().requires_grad_(True)
+            loss = G.compute_sinkhorn_loss(real, fk, cases.SC, 0.8, 100, f["h_fake"], f["m_real"], f["h_real"], f["m_fake"])
+            (grads[mode],) = torch.autograd.grad(loss, fk)
     scale = float(grads["block"].abs().max())
     assert float((grads["tile"] - grads["block"]).abs().max()) <= 1e-6 * scale
 
 
-def test_video_gradient_bf16_split_matches_f32_mfma(G):
+def test_video_gradient_bf16_split_matches_f32_mfma(G, L):
     """dfake = W [X;Y] on the bf16 matrix pipe (exact three-way split of W and of the videos, the default) against
-    the f32-input MFMA kernel (KCCOT_APPLY_F32=1) at configs[1] full size and at a blocked batch (B = 128)."""
+    the f32-input MFMA kernel (option "apply_f32" = 1) at configs[1] full size and at a blocked batch (B = 128)."""
     for shape in ((64, 64, 30, 64, 1), (128, 16, 10, 16, 3)):
         B, H, T, W, C = shape
         gen = torch.Generator(device=DEV).manual_seed(17 + B)
@@ -1193,13 +1170,9 @@ def test_video_gradient_bf16_split_matches_f32_mfma(G):
         f = {k: torch.rand((B, T, 8), device=DEV, generator=gen) for k in ("h_fake", "m_real", "h_real", "m_fake")}
         grads = {}
         for mode in ("x3", "f32"):
-            if mode == "f32":
-                os.environ["KCCOT_APPLY_F32"] = "1"
-            try:
+            with L.options(apply_f32=1 if mode == "f32" else 0):
                 fk = fake.clone().requires_grad_(True)
                 loss = G.compute_sinkhorn_loss(real, fk, cases.SC, 0.8, 100, f["h_fake"], f["m_real"], f["h_real"], f["m_fake"])
                 (grads[mode],) = torch.autograd.grad(loss, fk)
-            finally:
-                os.environ.pop("KCCOT_APPLY_F32", None)
         scale = float(grads["f32"].abs().max())
         assert float((grads["x3"] - grads["f32"]).abs().max()) < 2e-6 * scale

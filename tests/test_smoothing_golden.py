@@ -94,16 +94,17 @@ def test_hip_smoothing_matches_reference_fixtures(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["c3_r3_s5", "c1_r4_s5"])
-def test_hip_smoothing_legacy_path_matches_reference_fixtures(name, monkeypatch):
-    """The LDS-plane / per-axis fallback kernels (KCCOT_SMOOTH_NO_STREAM=1) against the same fixtures."""
+def test_hip_smoothing_legacy_path_matches_reference_fixtures(name):
+    """The LDS-plane / per-axis fallback kernels (option "smooth_stream" = 0) against the same fixtures."""
     import torch
+    from kccotgan_amd import _lib
     from kccotgan_amd.data_utils import KernelSmoothing
-    monkeypatch.setenv("KCCOT_SMOOTH_NO_STREAM", "1")
     g, v, tk, sk, sigma = load(name)
     ks = KernelSmoothing(temporal_kernel_size=tk, spatial_kernel_size=sk)
     x = torch.from_numpy(v).cuda()
-    np.testing.assert_allclose(ks.temporal_convolution(x, sigma).cpu().numpy(), g["temporal"], rtol=0, atol=ATOL_T)
-    np.testing.assert_allclose(ks.gaussian_convolution3D(x, sigma).cpu().numpy(), g["conv3d"], rtol=0, atol=ATOL_3D)
+    with _lib.options(smooth_stream=0):
+        np.testing.assert_allclose(ks.temporal_convolution(x, sigma).cpu().numpy(), g["temporal"], rtol=0, atol=ATOL_T)
+        np.testing.assert_allclose(ks.gaussian_convolution3D(x, sigma).cpu().numpy(), g["conv3d"], rtol=0, atol=ATOL_3D)
 
 
 @pytest.mark.gpu
@@ -176,48 +177,12 @@ def test_hip_smoothing_random_shapes_against_the_pinned_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(64, 64, 30, 64, 1), (8, 16, 12, 16, 3), (3, 9, 7, 10, 2), (2, 40, 33, 12, 1)])
-def test_single_launch_smoothing_equals_the_two_pass_form(shape, monkeypatch):
-    """KCCOT_SMOOTH_COOP=1 (opt-in: measured slower than the two passes) runs the final stage as ONE
-    launch -- the smoothed lines stay in registers across a device-wide barrier, the workgroups exchange their maxima and
-    write s / max (WALK_COOP) -- when the tensor fits the device's register files; a capacity the launch does not fit
-    (KCCOT_SMOOTH_COOP_MAX_WG) falls back.  The default is the two-pass form (maxima; recompute + divide, the block maxima
-    reduced by every workgroup of the second pass).  Same stencil arithmetic, same maximum: outputs and maxima are
-    bit-identical, the maximum of the output is exactly 1."""
-    import torch
-    from kccotgan_amd import _lib
-    from kccotgan_amd._lib import lib, ptr, check, workspace, stream_of
-    rng = np.random.default_rng(sum(shape))
-    x = torch.from_numpy(rng.random(shape, dtype=np.float32)).cuda()
-    B, H, T, W, C = shape
-    wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
-    wst = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    ws = wst.data_ptr()
-    for axes, radius in ((_lib.SMOOTH_T, 3), (_lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W, 3), (_lib.SMOOTH_T, 4),
-                         (_lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W, 4)):
-        outs, maxes = [], []
-        for env in ({}, {"KCCOT_SMOOTH_COOP": "1"}, {"KCCOT_SMOOTH_COOP": "1", "KCCOT_SMOOTH_COOP_MAX_WG": "1"}):
-            for k in ("KCCOT_SMOOTH_COOP", "KCCOT_SMOOTH_COOP_MAX_WG"):
-                monkeypatch.delenv(k, raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            wst.fill_(0x5a)                                # the launch must not depend on what the workspace held
-            o = torch.empty_like(x); m = torch.full((1,), -7.0, device=x.device)
-            check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 1.7, radius, axes, ptr(o), ptr(m), ws, wsb, stream_of(x)), "smooth")
-            torch.cuda.synchronize()
-            outs.append(o); maxes.append(float(m))
-        assert float(outs[0].max()) == 1.0
-        assert maxes[0] == maxes[1] == maxes[2] and np.isfinite(maxes[0])
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (shape, axes, radius)
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(64, 64, 30, 64, 1), (3, 9, 7, 8, 1), (2, 12, 32, 16, 1), (5, 7, 11, 32, 1), (1, 10, 9, 128, 1),
                                    (2, 8, 6, 256, 1), (37, 5, 8, 64, 1)])
-def test_fused_t_and_w_stage_equals_the_two_kernels(shape, monkeypatch):
+def test_fused_t_and_w_stage_equals_the_two_kernels(shape):
     """3-D smoothing, C = 1, W/4 a power of two: the T walk applies the W stencil to every T-smoothed piece before storing it
     (neighbour pieces = neighbouring lanes' registers, DPP wave shifts) instead of a T kernel and a W kernel with a round
-    trip of the tensor in between (KCCOT_SMOOTH_NO_TW=1).  Same fma order: bit-identical outputs, radius 3 and 4."""
+    trip of the tensor in between (option "smooth_fused_tw" = 0).  Same fma order: bit-identical outputs, radius 3 and 4."""
     import torch
     from kccotgan_amd import _lib
     from kccotgan_amd._lib import lib, ptr, check, stream_of
@@ -234,14 +199,11 @@ def test_fused_t_and_w_stage_equals_the_two_kernels(shape, monkeypatch):
             continue
         outs = []
         for no_tw in (False, True):
-            if no_tw:
-                monkeypatch.setenv("KCCOT_SMOOTH_NO_TW", "1")
-            else:
-                monkeypatch.delenv("KCCOT_SMOOTH_NO_TW", raising=False)
-            o = torch.empty_like(x); m = torch.empty(1, device=x.device)
-            check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 1.7, radius, axes, ptr(o), ptr(m), wst.data_ptr(), wsb, stream_of(x)),
-                  "smooth")
-            torch.cuda.synchronize()
+            with _lib.options(smooth_fused_tw=0 if no_tw else 1):
+                o = torch.empty_like(x); m = torch.empty(1, device=x.device)
+                check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 1.7, radius, axes, ptr(o), ptr(m), wst.data_ptr(), wsb, stream_of(x)),
+                      "smooth")
+                torch.cuda.synchronize()
             outs.append(o)
         assert torch.equal(outs[0], outs[1]), (shape, radius)
         np.testing.assert_allclose(outs[0].cpu().numpy(), sm.gaussian_convolution3D_separable(v, 1.7, radius), rtol=0, atol=ATOL_3D)
@@ -249,12 +211,13 @@ def test_fused_t_and_w_stage_equals_the_two_kernels(shape, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(4, 16, 12, 16, 1), (2, 9, 30, 64, 1), (3, 20, 7, 8, 1), (2, 64, 30, 64, 1)])
-def test_generic_kernels_equal_the_specialised_ones(shape, monkeypatch):
-    """KCCOT_SMOOTH_GENERIC=1 routes every stage through the any-length / any-channel kernels (smooth_roll, smooth_wrow)
+def test_generic_kernels_equal_the_specialised_ones(shape):
+    """Option "smooth_generic" = 1 routes every stage through the any-length / any-channel kernels (smooth_roll, smooth_wrow)
     that serve the shapes the specialised kernels cannot take (C > 1 on the W axis, axes longer than 64).  On shapes both
     families accept: same loads, same fma order -> the forward is bit-identical; the adjoint builds its border weights in
     a different order (table vs in-line folds) and agrees to rounding."""
     import torch
+    from kccotgan_amd import _lib
     from kccotgan_amd.data_utils import KernelSmoothing
     rng = np.random.default_rng(sum(shape) + 5)
     v = rng.random(shape, dtype=np.float32)
@@ -265,15 +228,12 @@ def test_generic_kernels_equal_the_specialised_ones(shape, monkeypatch):
         ks = KernelSmoothing(ksize, ksize)
         res = {}
         for mode in ("special", "generic"):
-            if mode == "generic":
-                monkeypatch.setenv("KCCOT_SMOOTH_GENERIC", "1")
-            else:
-                monkeypatch.delenv("KCCOT_SMOOTH_GENERIC", raising=False)
-            x = torch.from_numpy(v).cuda().requires_grad_(True)
-            t = ks.temporal_convolution(x, 2.1)
-            (gt,) = torch.autograd.grad(t, x, gr)
-            c = ks.gaussian_convolution3D(x, 2.1)
-            (gc,) = torch.autograd.grad(c, x, gr)
+            with _lib.options(smooth_generic=1 if mode == "generic" else 0):
+                x = torch.from_numpy(v).cuda().requires_grad_(True)
+                t = ks.temporal_convolution(x, 2.1)
+                (gt,) = torch.autograd.grad(t, x, gr)
+                c = ks.gaussian_convolution3D(x, 2.1)
+                (gc,) = torch.autograd.grad(c, x, gr)
             res[mode] = (t.detach(), c.detach(), gt, gc)
         assert torch.equal(res["special"][0], res["generic"][0]), (shape, ksize, "temporal")
         assert torch.equal(res["special"][1], res["generic"][1]), (shape, ksize, "3-D")
@@ -285,11 +245,12 @@ def test_generic_kernels_equal_the_specialised_ones(shape, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(3, 8, 12, 16, 3), (2, 9, 30, 64, 3), (2, 5, 7, 10, 2), (1, 6, 9, 33, 1), (2, 7, 48, 128, 3),
                                    (2, 4, 5, 6, 5), (2, 64, 30, 64, 1), (2, 5, 40, 96, 3), (3, 6, 9, 12, 4), (2, 6, 8, 20, 1)])
-def test_fused_t_w_plane_kernel_equals_the_separate_stages(shape, monkeypatch):
-    """3-D smoothing with the (b, h) plane staged in LDS (smooth_tw_plane: T and W stencils in one pass, any channel count;
-    adjoint: W^T and T^T) against the separate per-axis kernels (KCCOT_SMOOTH_NO_TWPLANE=1).  Forward: same fma order,
-    bit-identical.  Adjoint: agrees to rounding, and both against the fp64 autograd of the pinned oracle."""
+def test_fused_t_w_plane_kernel_equals_the_separate_stages(shape):
+    """3-D smoothing with the (b, h) plane staged in LDS (smooth_tw_plane: T and W stencils in one pass, any channel
+    count) against the separate per-axis kernels (option "smooth_fused_tw" = 0).  Forward: same fma order, bit-identical.
+    The adjoint (always the separate stages) against the fp64 autograd of the pinned oracle."""
     import torch
+    from kccotgan_amd import _lib
     from kccotgan_amd.data_utils import KernelSmoothing
     from oracle import smoothing_torch as st
     rng = np.random.default_rng(sum(shape) + 11)
@@ -302,16 +263,10 @@ def test_fused_t_w_plane_kernel_equals_the_separate_stages(shape, monkeypatch):
         ks = KernelSmoothing(ksize, ksize)
         res = {}
         for mode in ("plane", "separate"):
-            if mode == "separate":
-                monkeypatch.setenv("KCCOT_SMOOTH_NO_TWPLANE", "1")
-                monkeypatch.setenv("KCCOT_SMOOTH_NO_TW", "1")
-            else:
-                monkeypatch.delenv("KCCOT_SMOOTH_NO_TWPLANE", raising=False)
-                monkeypatch.delenv("KCCOT_SMOOTH_NO_TW", raising=False)
-            monkeypatch.setenv("KCCOT_SMOOTH_TWPLANE_BWD", "1")      # the adjoint form is opt-in (measured slower)
-            x = torch.from_numpy(v).cuda().requires_grad_(True)
-            c = ks.gaussian_convolution3D(x, 1.9)
-            (gc,) = torch.autograd.grad(c, x, gr)
+            with _lib.options(smooth_fused_tw=0 if mode == "separate" else 1):
+                x = torch.from_numpy(v).cuda().requires_grad_(True)
+                c = ks.gaussian_convolution3D(x, 1.9)
+                (gc,) = torch.autograd.grad(c, x, gr)
             res[mode] = (c.detach(), gc)
         assert torch.equal(res["plane"][0], res["separate"][0]), (shape, ksize)
         a, b = res["plane"][1], res["separate"][1]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-only timing of the video-gradient stage (kccot_pairwise_cost3_bwd_f32) at a large batch.
-usage: bench_apply.py [B H T W C]; env: KCCOT_APPLY_NO_M256, KCCOT_APPLY_DIAG (timing experiments)"""
+usage: bench_apply.py [B H T W C]; options through KCCOT_OPTIONS (apply_m256=0, apply_f32=1)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,4 +23,4 @@ for _ in range(reps): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 fl = 2.0 * B * 2 * B * K * 6
-print("B=%d K=%d: %.3f ms  (%.2f PFLOP/s bf16 executed)  DIAG=%s NO_M256=%s" % (B, K, ms, fl / ms / 1e12, os.environ.get("KCCOT_APPLY_DIAG", "0"), os.environ.get("KCCOT_APPLY_NO_M256", "0")))
+print("B=%d K=%d: %.3f ms  (%.2f PFLOP/s bf16 executed)  KCCOT_OPTIONS=%s" % (B, K, ms, fl / ms / 1e12, os.environ.get("KCCOT_OPTIONS", "")))

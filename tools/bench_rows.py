@@ -5,7 +5,7 @@ usage: bench_rows.py [G ...]   (default 1 2 4 8)"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
+os.environ["KCCOT_OPTIONS"] = "sinkhorn_shortcut=0"
 import torch
 import bench
 from kccotgan_amd.dist import HipOps as H

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-only timing of the Sinkhorn forward / reverse sweep at configs[1] size (three 64x64 problems).
-usage: bench_sinkhorn.py [near|far] ; env knobs: KCCOT_SK_NO_SHORTCUT, KCCOT_SK_LPR"""
+usage: bench_sinkhorn.py [near|far] ; options through KCCOT_OPTIONS (sinkhorn_shortcut=0, sinkhorn_lanes_per_line=8, ...)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,5 +31,5 @@ if lib.kccot_sinkhorn_fused_eligible(n, L):
     tfu = timeit(fused)
     bwd(); torch.cuda.synchronize()
     print("%s: fused solve+sweep %.1f us (%.3f us per half-step over %d)  LPR=%s  max|dC_fused - dC_two_kernel| %.3g of %.3g" % (
-        regime, tfu, tfu / (4 * max(nits[3:].tolist())), 4 * max(nits[3:].tolist()), os.environ.get("KCCOT_SK_LPR", "default"),
+        regime, tfu, tfu / (4 * max(nits[3:].tolist())), 4 * max(nits[3:].tolist()), os.environ.get("KCCOT_OPTIONS", "defaults"),
         float((dCu - dC).abs().max()), float(dC.abs().max())))

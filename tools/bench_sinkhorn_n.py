@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Kernel-only timing of the multi-CU Sinkhorn solvers (128 < n <= 1024): counter-barrier kernels vs the
-flag-in-data kernels, with and without the one-XCD-per-problem mapping.  Also checks that the variants agree.
+"""Kernel-only timing of the Sinkhorn solvers for 128 < n <= 1024: the multi-CU flag-in-data kernels vs the
+one-workgroup streaming kernels (option sinkhorn_coop).  Also checks that the variants agree.
 usage: bench_sinkhorn_n.py [n ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,8 +8,8 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from kccotgan_amd._lib import lib, ptr
 
-VARIANTS = {"barrier": {"KCCOT_SK_COOP_BARRIER": "1"}, "ll": {}, "ll+xcd": {"KCCOT_SK_COOP_XCD": "1"}}
-KEYS = ("KCCOT_SK_COOP_BARRIER", "KCCOT_SK_COOP_XCD")
+from kccotgan_amd import _lib
+VARIANTS = {"multi-CU (flag-in-data)": dict(sinkhorn_coop=1), "one workgroup (streaming)": dict(sinkhorn_coop=0)}
 
 
 def run(n, L=100):
@@ -31,21 +31,18 @@ def run(n, L=100):
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3
     res = {}
-    for name, env in VARIANTS.items():
-        for k in KEYS: os.environ.pop(k, None)
-        os.environ.update(env)
-        tf = timeit(fwd); tb = timeit(bwd)
+    for name, kv in VARIANTS.items():
+        with _lib.options(**kv):
+            tf = timeit(fwd); tb = timeit(bwd)
         res[name] = (cost.cpu().numpy().copy(), nits.cpu().numpy().copy(), uh.cpu().numpy().copy(), dC.cpu().numpy().copy())
-        print("n=%d %-8s fwd %8.1f us (%.2f us/iter)  bwd %8.1f us  nits %s cost %s" % (
+        print("n=%d %-26s fwd %8.1f us (%.2f us/iter)  bwd %8.1f us  nits %s cost %s" % (
             n, name, tf, tf / L, tb, nits.tolist()[:3], [round(c, 5) for c in cost.tolist()]), flush=True)
-    for k in KEYS: os.environ.pop(k, None)
-    ref = res["barrier"]
-    for name in ("ll", "ll+xcd"):
-        r = res[name]
-        print("   %-7s vs barrier: cost rel %.2e  nits equal %s  u_hist max|d| %.2e  dC max|d|/max %.2e  finite %s" % (
-            name, float(np.abs(r[0] - ref[0]).max() / np.abs(ref[0]).max()), bool((r[1] == ref[1]).all()),
-            float(np.abs(r[2] - ref[2]).max()), float(np.abs(r[3] - ref[3]).max() / np.abs(ref[3]).max()),
-            bool(np.isfinite(r[3]).all())), flush=True)
+    names = list(VARIANTS)
+    ref, r = res[names[0]], res[names[1]]
+    print("   streaming vs multi-CU: cost rel %.2e  nits equal %s  u_hist max|d| %.2e  dC max|d|/max %.2e  finite %s" % (
+        float(np.abs(r[0] - ref[0]).max() / np.abs(ref[0]).max()), bool((r[1] == ref[1]).all()),
+        float(np.abs(r[2] - ref[2]).max()), float(np.abs(r[3] - ref[3]).max() / np.abs(ref[3]).max()),
+        bool(np.isfinite(r[3]).all())), flush=True)
 
 
 for n in [int(a) for a in sys.argv[1:]] or [256, 512, 1024, 200]:

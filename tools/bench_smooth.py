@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-only timing of KernelSmoothing forward (temporal and 3-D) at a BASELINE shape, HIP events around `reps` calls.
-usage: bench_smooth.py [B H T W C]   env: KCCOT_SMOOTH_COOP=1 (single-launch final stage)"""
+usage: bench_smooth.py [B H T W C]   options through KCCOT_OPTIONS (smooth_stream=0, smooth_generic=1, smooth_fused_tw=0)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,5 +23,5 @@ for name, axes in (("temporal", _lib.SMOOTH_T), ("conv3d", _lib.SMOOTH_T | _lib.
     for _ in range(reps): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
-    print("%-8s B=%d %dx%dx%d T=%d: %.1f us  (%.2f TB/s algorithmic = %.3f of 8 TB/s)  max %.6f  COOP=%s" % (
-        name, B, H, W, C, T, us, 8.0 * n / us / 1e6, 8.0 * n / us / 1e6 / 8.0, float(m), os.environ.get("KCCOT_SMOOTH_COOP", "0")))
+    print("%-8s B=%d %dx%dx%d T=%d: %.1f us  (%.2f TB/s algorithmic = %.3f of 8 TB/s)  max %.6f  KCCOT_OPTIONS=%s" % (
+        name, B, H, W, C, T, us, 8.0 * n / us / 1e6, 8.0 * n / us / 1e6 / 8.0, float(m), os.environ.get("KCCOT_OPTIONS", "")))

@@ -2,7 +2,7 @@
 # One GPU-box session: parity tests, smoke, bench, rocprof summary.  Usage: tools/gpu_ci.sh [tag]
 # Stops at the first step that is killed or times out (never starts another GPU step after that).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 step() {  # name, timeout, command...

@@ -33,7 +33,7 @@ for shape, seed, regime in cases.CASES:
     for path in ("auto", "direct", "mfma", "mfma_f32"):
         if path.startswith("mfma") and (K % 4 or K < 32):
             continue
-        os.environ["KCCOT_GRAM_F32"] = "1" if path == "mfma_f32" else "0"
+        L.set_option("gram_f32", 1 if path == "mfma_f32" else 0)
         G.cost_flags = {"auto": 0, "direct": L.COST_FORCE_DIRECT, "mfma": L.COST_FORCE_MFMA, "mfma_f32": L.COST_FORCE_MFMA}[path]
         t = {k: torch.from_numpy(v).cuda() for k, v in inp.items()}
         for k in WRT:

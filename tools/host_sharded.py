@@ -4,7 +4,7 @@ or host-bound?  Compare with tools/bench_rows.py's device sum for G = 1."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["KCCOT_SK_NO_SHORTCUT"] = "1"
+os.environ["KCCOT_OPTIONS"] = "sinkhorn_shortcut=0"
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29512")
 os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 import torch, torch.distributed as dist

@@ -7,7 +7,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$ROOT"
-VARIANTS="0 1 2 3 4 7 8 16 19 23"
+VARIANTS="0 1 2 4 16 19"
 if [ "$1" = "build" ]; then
     mkdir -p build/abl
     python3 - <<'PY'
