@@ -288,6 +288,12 @@ def time_smoothing(dev):
     for name, c in OTHER_CONFIGS.items():
         shapes[name] = c[:5]
     out = {}
+    # HBM-side traffic per call from the committed counter passes (tools/pmc_smooth.sh -> profiles/smooth_traffic.json):
+    # every smoothing kernel moves its tensor exactly once, so the ratio is the number of tensor passes over the minimum
+    traffic = {}
+    tf_path = os.path.join(ROOT, "profiles", "smooth_traffic.json")
+    if os.path.exists(tf_path):
+        traffic = json.load(open(tf_path)).get("calls", {})
     for name, (B, H, T, W, C) in shapes.items():
         n = B * H * T * W * C
         if n * 4 * 5 > 60e9:
@@ -307,6 +313,10 @@ def time_smoothing(dev):
             tb = time_launches(bwd, reps=reps, warm=3)
             rec[key] = {"fwd_us": tf, "bwd_us": tb, "fwd_hbm_frac": 8.0 * n / (tf * 1e-6) / (HBM_PEAK_GBS * 1e9),
                         "bwd_hbm_frac": 12.0 * n / (tb * 1e-6) / (HBM_PEAK_GBS * 1e9)}
+            for d in ("fwd", "bwd"):
+                t_rec = traffic.get("%dx%dx%dx%dx%d_%s_%s" % (B, H, T, W, C, key, d))
+                if t_rec:
+                    rec[key][d + "_traffic_over_algorithmic"] = t_rec["traffic_over_algorithmic"]
         out[name] = rec
         del x, g, o, d, ws
         torch.cuda.empty_cache()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-only timing of KernelSmoothing forward (temporal and 3-D) at a BASELINE shape, HIP events around `reps` calls.
-usage: bench_smooth.py [B H T W C]   options through KCCOT_OPTIONS (smooth_stream=0, smooth_generic=1, smooth_fused_tw=0)"""
+usage: bench_smooth.py [B H T W C [temporal|conv3d]]   options through KCCOT_OPTIONS (smooth_stream=0, smooth_generic=1, smooth_fused_tw=0)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,12 +8,15 @@ import torch
 from kccotgan_amd import _lib
 from kccotgan_amd._lib import lib, ptr, check
 B, H, T, W, C = (int(a) for a in sys.argv[1:6]) if len(sys.argv) > 5 else (64, 64, 30, 64, 1)
+ONLY = sys.argv[6] if len(sys.argv) > 6 else None            # "temporal" or "conv3d": time that call only (PMC passes)
 x = torch.rand(B, H, T, W, C, device="cuda")
 o = torch.empty_like(x); m = torch.empty(1, device="cuda")
 wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
 wst = torch.empty(wsb, dtype=torch.uint8, device="cuda")
 n = x.numel()
 for name, axes in (("temporal", _lib.SMOOTH_T), ("conv3d", _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W)):
+    if ONLY and name != ONLY:
+        continue
     def run(): check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 5.0, 3, axes, ptr(o), ptr(m), wst.data_ptr(), wsb, None), "smooth")
     for _ in range(5): run()
     torch.cuda.synchronize()
