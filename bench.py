@@ -313,10 +313,10 @@ def time_smoothing(dev):
             tb = time_launches(bwd, reps=reps, warm=3)
             rec[key] = {"fwd_us": tf, "bwd_us": tb, "fwd_hbm_frac": 8.0 * n / (tf * 1e-6) / (HBM_PEAK_GBS * 1e9),
                         "bwd_hbm_frac": 12.0 * n / (tb * 1e-6) / (HBM_PEAK_GBS * 1e9)}
-            for d in ("fwd", "bwd"):
-                t_rec = traffic.get("%dx%dx%dx%dx%d_%s_%s" % (B, H, T, W, C, key, d))
+            for direction in ("fwd", "bwd"):
+                t_rec = traffic.get("%dx%dx%dx%dx%d_%s_%s" % (B, H, T, W, C, key, direction))
                 if t_rec:
-                    rec[key][d + "_traffic_over_algorithmic"] = t_rec["traffic_over_algorithmic"]
+                    rec[key][direction + "_traffic_over_algorithmic"] = t_rec["traffic_over_algorithmic"]
         out[name] = rec
         del x, g, o, d, ws
         torch.cuda.empty_cache()
@@ -324,27 +324,40 @@ def time_smoothing(dev):
 
 
 def sharded_config(name, rank, world, dev, dist, barrier, steps=5):
-    """The batch-sharded step (kccotgan_amd.dist, gather protocol unless KCCOT_DIST_PROTOCOL says otherwise) of the
-    BASELINE config that names this GPU count, global batch fixed (strong scaling of that config)."""
+    """The batch-sharded step (kccotgan_amd.dist) of the BASELINE config that names this GPU count, global batch fixed
+    (strong scaling of that config), timed with EVERY protocol the shape supports: `gather` (all-gather the batch, row
+    blocks on the matrix pipe -- what BASELINE.json's north star prescribes) and `ksplit` (all-to-all into K-slices,
+    all-reduced fp64 Gram sums).  Neither has been timed on more than one GPU before the first SCALE run: the record of
+    both is what decides the default."""
     from kccotgan_amd import dist as kd
     B, H, T, W, C, L, ngpu = OTHER_CONFIGS[name]
     Bl = B // world
+    K = H * T * W * C
     t = config_inputs(Bl, H, T, W, C, dev, seed=100 + rank)       # this rank's shard only
     shard = {k: v.requires_grad_(k != "real") for k, v in t.items()}
-    step = lambda: kd.sharded_loss_step(shard, SC, epsilon=1.0, L=L)
-    loss, _ = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss, _g = step()
-    barrier()
-    el = time.perf_counter() - t0
-    tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    K = H * T * W * C
-    return {"B": B, "K": K, "L": L, "n_gpus_here": world, "ms_fwd_bwd": float(tt) / steps * 1e3, "steps": steps,
-            "protocol": os.environ.get("KCCOT_DIST_PROTOCOL", "gather"), "loss": float(loss),
-            "sinkhorn_iters": kd.last_info["nits"].tolist() if "nits" in kd.last_info else None}
+    protocols = ["gather"] + (["ksplit"] if kd.ksplit_supported(B, K, world) else [])
+    rec = {"B": B, "K": K, "L": L, "n_gpus_here": world, "steps": steps, "protocols": {}}
+    for proto in protocols:
+        step = lambda: kd.sharded_loss_step(shard, SC, epsilon=1.0, L=L, protocol=proto)
+        try:
+            loss, _ = step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss, _g = step()
+            barrier()
+            el = time.perf_counter() - t0
+            tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            rec["protocols"][proto] = {"ms_fwd_bwd": float(tt) / steps * 1e3, "loss": float(loss),
+                                       "sinkhorn_iters": kd.last_info["nits"].tolist() if "nits" in kd.last_info else None}
+        except Exception as e:           # one protocol failing must not cost the other's record (all ranks fail alike)
+            rec["protocols"][proto] = {"error": repr(e)}
+    ok = {k: v["ms_fwd_bwd"] for k, v in rec["protocols"].items() if "ms_fwd_bwd" in v}
+    if ok:
+        best = min(ok, key=ok.get)
+        rec["ms_fwd_bwd"], rec["protocol"] = ok[best], best
+    return rec
 
 
 def main():

@@ -136,6 +136,26 @@ int kccot_pairwise_cost3_rows_f32(const float* real, const float* fake, int B, i
                                   const float* m_fake, int T, int J, int row_begin, int row_count,
                                   float* C3_rows, void* ws, size_t ws_bytes, kccot_stream_t stream);
 
+/* The same row blocks on the matrix pipe (round 3; what the batch-sharded caller runs for B > 64): the rank forms the Gram
+ * row block [X_I ; E_I] [X ; E]^T (E = fake - real) with the exact bf16 split of the single-GPU kernels and combines it
+ * in fp64 with the pair-difference identities.  Those need x_j.x_j, e_j.e_j, x_j.e_j of EVERY sample j:
+ *   kccot_row_norms_f64 writes them for `rows` rows as [rows,3] doubles (each rank: its own rows, from its local shard,
+ *   before the all-gather of the videos; with a workspace of kccot_row_norms_workspace_bytes(rows) a row is split over
+ *   several workgroups, with ws = NULL one workgroup sums a whole row); the caller all-gathers the 3 B doubles and passes them as `norms` [B,3].
+ *   norms == NULL: the call computes them for all B rows itself (one more pass over both videos).
+ * Supported (kccot_pairwise_cost3_rows_gram_supported): row_count 32 or 64, B % 128 == 0, K % 4 == 0, 256 <= K <= 2^22;
+ * otherwise use kccot_pairwise_cost3_rows_f32.  Results agree with it to fp32 rounding (1e-5 of max|C|). */
+int kccot_pairwise_cost3_rows_gram_supported(int row_count, int B, int64_t K);
+size_t kccot_pairwise_cost3_rows_gram_workspace_bytes(int row_count, int B, int64_t K);
+size_t kccot_row_norms_workspace_bytes(int rows);
+int kccot_row_norms_f64(const float* real, const float* fake, int rows, int64_t K, double* norms_out,
+                        void* ws, size_t ws_bytes, kccot_stream_t stream);
+int kccot_pairwise_cost3_rows_gram_f32(const float* real, const float* fake, int B, int64_t K, float sc,
+                                       const float* h_fake, const float* h_real, const float* m_real,
+                                       const float* m_fake, int T, int J, int row_begin, int row_count,
+                                       const double* norms, float* C3_rows, void* ws, size_t ws_bytes,
+                                       kccot_stream_t stream);
+
 /* Backward of the three cost matrices: given g3 = dLoss/dC3 [3,B,B] writes
  *   dfake [B,K] (may be NULL), dh_fake, dh_real, dm_real, dm_fake [B,T,J] (each may be NULL).
  * real never receives a gradient (kernel_train.py:252,289). */

@@ -41,6 +41,11 @@ SIGNATURES = {
     "kccot_pairwise_cost3_gram_sums_span": (_i, [_i, _i64, _c.POINTER(_sz), _c.POINTER(_sz)]),
     "kccot_pairwise_cost3_rows_workspace_bytes": (_sz, [_i, _i, _i64]),
     "kccot_pairwise_cost3_rows_f32": (_i, [_fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _sz, _fp]),
+    "kccot_pairwise_cost3_rows_gram_supported": (_i, [_i, _i, _i64]),
+    "kccot_pairwise_cost3_rows_gram_workspace_bytes": (_sz, [_i, _i, _i64]),
+    "kccot_row_norms_workspace_bytes": (_sz, [_i]),
+    "kccot_row_norms_f64": (_i, [_fp, _fp, _i, _i64, _fp, _fp, _sz, _fp]),
+    "kccot_pairwise_cost3_rows_gram_f32": (_i, [_fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _sz, _fp]),
     "kccot_pairwise_cost3_bwd_workspace_bytes": (_sz, [_i, _i64]),
     "kccot_pairwise_cost3_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i,
                                           _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
@@ -201,7 +206,7 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise KccotError("kccotgan_amd needs tensors on a ROCm device (got %s); there is no CPU path" % t.device)
-    if t.dtype != torch.float32 and t.dtype != torch.int32:
+    if t.dtype not in (torch.float32, torch.int32, torch.float64):      # float64: the Gram sums / row norms of the sharded path
         raise TypeError("kccotgan_amd kernels are fp32 (got %s)" % t.dtype)
     if not t.is_contiguous():
         raise ValueError("kccotgan_amd kernels need contiguous tensors")

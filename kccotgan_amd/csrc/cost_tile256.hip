@@ -28,19 +28,14 @@
 #include "common.h"
 #include "cost_internal.h"
 #include "options.h"
+#include "gram_q.h"
 
 namespace kccot {
 
-typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
-typedef float qf32x16 __attribute__((ext_vector_type(16)));
-
 constexpr int QP = 256;                    // rows of a panel
-constexpr int QROWB = 32;                  // bytes of one row of one plane of a 16-k step
 constexpr int QPLANE = 2 * QP * QROWB;     // 16384 bytes: A panel rows 0..255, B panel rows 256..511
 constexpr int QSLOT = 3 * QPLANE;          // 49152 bytes per step
 constexpr int QELEMS = QP * QP;
-constexpr int QG = 32;                     // columns per load granule = two steps
-constexpr int Q_MAX_GRAN = 48;             // granules per K-chunk (1536 columns, 576 MFMA accumulations per partial tile)
 
 struct Q256Args {
     const float* x;       // real [B,K]
@@ -52,34 +47,6 @@ struct Q256Args {
 };
 
 __host__ __device__ inline int q256_pair_slot(int nt, int pa, int pb) { return pa * nt - (pa * (pa - 1)) / 2 + (pb - pa); }
-
-// split two floats exactly into three bf16 pieces each; dword = bf16(a) | bf16(b) << 16 per plane (tsplit3_store's pieces)
-__device__ __forceinline__ void q256_split_store(unsigned char* zs, int off, float a, float b) {
-    const unsigned xa = __float_as_uint(a), xb = __float_as_uint(b);
-    const float ra = a - __uint_as_float(xa & 0xFFFF0000u), rb = b - __uint_as_float(xb & 0xFFFF0000u);      // exact
-    const unsigned ma = __float_as_uint(ra), mb = __float_as_uint(rb);
-    const float la = ra - __uint_as_float(ma & 0xFFFF0000u), lb = rb - __uint_as_float(mb & 0xFFFF0000u);      // exact, <= 8 bits
-    *reinterpret_cast<unsigned*>(zs + off) = __builtin_amdgcn_perm(xb, xa, 0x07060302u);
-    *reinterpret_cast<unsigned*>(zs + QPLANE + off) = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
-    *reinterpret_cast<unsigned*>(zs + 2 * QPLANE + off) = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
-}
-
-struct QFrag { qbf16x8 h, m, l; };
-__device__ __forceinline__ QFrag q256_frag(const unsigned char* zs, int off) {
-    QFrag f;
-    f.h = *reinterpret_cast<const qbf16x8*>(zs + off);
-    f.m = *reinterpret_cast<const qbf16x8*>(zs + QPLANE + off);
-    f.l = *reinterpret_cast<const qbf16x8*>(zs + 2 * QPLANE + off);
-    return f;
-}
-__device__ __forceinline__ void q256_mfma6(qf32x16& acc, const QFrag& a, const QFrag& b) {   // smallest terms first
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
-}
 
 // SAME (a diagonal pair, pa == pb: only panel A is staged) and RAGGED (K % 32 != 0: the last granule of the last chunk is
 // partial, values past K are zeroed) are template parameters so that the staging code of each form is straight-line and the
@@ -110,7 +77,6 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
         apanel = pa < a.nx ? a.x + (int64_t)pa * QP * K : a.e + (int64_t)(pa - a.nx) * QP * K;
         bpanel = pb < a.nx ? a.x + (int64_t)pb * QP * K : a.e + (int64_t)(pb - a.nx) * QP * K;
     }
-    typedef unsigned int qu32x4 __attribute__((ext_vector_type(4)));
     const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(apanel), 0, 0xFFFFFFFFu, 0x00020000);
     const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bpanel), 0, 0xFFFFFFFFu, 0x00020000);
     const auto re = __builtin_amdgcn_make_buffer_rsrc(a.e + (int64_t)pa * QP * K, 0, 0xFFFFFFFFu, 0x00020000);   // EPAIR only
@@ -151,14 +117,14 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(qu32x4, v), re, (int)vo, (int)((p - 8) * rstep), 0);
             }
             if (RAGGED) { v.x = kok ? v.x : 0.f; v.y = kok ? v.y : 0.f; v.z = kok ? v.z : 0.f; v.w = kok ? v.w : 0.f; }
-            q256_split_store(zs, woff + 32 * p * QROWB, v.x, v.y);
+            gq_split_store<QPLANE>(zs, woff + 32 * p * QROWB, v.x, v.y);
             carry[p] = make_float2(v.z, v.w);
         }
     };
     auto emit_odd = [&](unsigned char* zs) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            q256_split_store(zs, woff + 32 * p * QROWB, carry[p].x, carry[p].y);
+            gq_split_store<QPLANE>(zs, woff + 32 * p * QROWB, carry[p].x, carry[p].y);
         }
     };
 
@@ -188,27 +154,27 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
         if constexpr (SAME) {
             QFrag bf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = q256_frag(zs, boff + j * 32 * QROWB);
+            for (int j = 0; j < 4; ++j) bf[j] = gq_frag<QPLANE>(zs, boff + j * 32 * QROWB);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const QFrag af = q256_frag(zs, aoff + i * 32 * QROWB);
+                const QFrag af = gq_frag<QPLANE>(zs, aoff + i * 32 * QROWB);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) q256_mfma6(acc[4 * i + j], af, bf[j]);
+                for (int j = 0; j < 4; ++j) gq_mfma6(acc[4 * i + j], af, bf[j]);
             }
-            const QFrag ea = q256_frag(zs, eoff);                            // row tile `ter` = column tile `ter`: one fragment
-            q256_mfma6(acc[8], ea, ea);
-            const QFrag eb = q256_frag(zs, eoff + (wave < 2 ? 32 * QROWB : 0));
-            q256_mfma6(acc[9], ea, eb);
+            const QFrag ea = gq_frag<QPLANE>(zs, eoff);                            // row tile `ter` = column tile `ter`: one fragment
+            gq_mfma6(acc[8], ea, ea);
+            const QFrag eb = gq_frag<QPLANE>(zs, eoff + (wave < 2 ? 32 * QROWB : 0));
+            gq_mfma6(acc[9], ea, eb);
         } else {
             // two B tiles at a time (24 fragment registers instead of 48; the A fragments are read twice per step)
 #pragma unroll
             for (int jh = 0; jh < 2; ++jh) {
-                const QFrag b0 = q256_frag(zs, boff + (2 * jh) * 32 * QROWB), b1 = q256_frag(zs, boff + (2 * jh + 1) * 32 * QROWB);
+                const QFrag b0 = gq_frag<QPLANE>(zs, boff + (2 * jh) * 32 * QROWB), b1 = gq_frag<QPLANE>(zs, boff + (2 * jh + 1) * 32 * QROWB);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const QFrag af = q256_frag(zs, aoff + i * 32 * QROWB);
-                    q256_mfma6(acc[4 * i + 2 * jh], af, b0);
-                    q256_mfma6(acc[4 * i + 2 * jh + 1], af, b1);
+                    const QFrag af = gq_frag<QPLANE>(zs, aoff + i * 32 * QROWB);
+                    gq_mfma6(acc[4 * i + 2 * jh], af, b0);
+                    gq_mfma6(acc[4 * i + 2 * jh + 1], af, b1);
                 }
             }
         }

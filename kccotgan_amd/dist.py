@@ -4,7 +4,9 @@ GPU, torch.distributed over RCCL/xGMI).  The reference has no distributed code a
 
   1. every rank owns B/G samples of real / fake and of the four feature tensors;
   2. ALL-GATHER the video shards and the (KB-sized) features -> every rank holds [B,K] of both;
-  3. rank g builds the ROW BLOCKS C_xy[I_g,:], C_xx[I_g,:], C_yy[I_g,:] ([B/G, B] each);
+  3. rank g builds the ROW BLOCKS C_xy[I_g,:], C_xx[I_g,:], C_yy[I_g,:] ([B/G, B] each) -- on the matrix pipe
+     (csrc/cost_rows.hip) when it owns 32 or 64 samples and B % 128 == 0: the Gram row block [X_I ; E_I][X ; E]^T plus the
+     all-gathered row norms x.x, e.e, x.e (3 doubles per sample); on the direct-difference kernel otherwise;
   4. ALL-GATHER the row blocks (3*B*B*4 bytes in total) -> the full cost matrices, replicated;
   5. every rank runs the identical (deterministic) Sinkhorn forward and reverse sweep: the loss
      and dLoss/dC are bitwise the same everywhere, no communication;
@@ -53,11 +55,35 @@ class HipOps:
         return C
 
     @staticmethod
-    def cost3_rows(real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, row_count):
-        """Row blocks [3, row_count, B] of (xy, xx, yy) in one launch (kccot_pairwise_cost3_rows_f32)."""
+    def rows_gram_supported(row_count, B, K):
+        """The row block on the matrix pipe (kccot_pairwise_cost3_rows_gram_f32): 32 or 64 rows per rank, B % 128 == 0.
+        Depends on (row_count, B, K) and the process-wide options only, so all ranks agree."""
+        return bool(lib.kccot_pairwise_cost3_rows_gram_supported(int(row_count), int(B), int(K)))
+
+    @staticmethod
+    def row_norms(real_l, fake_l):
+        """x.x, e.e, x.e (e = fake - real) of this rank's rows, [Bl,3] float64 -- the column-side diagonal Gram entries every
+        other rank's row block needs (all-gathered by the caller: 24 bytes per sample)."""
+        Bl, K = real_l.shape
+        out = _lib.empty((Bl, 3), torch.float64, real_l.device)
+        ws, wsb = workspace(lib.kccot_row_norms_workspace_bytes(Bl), real_l)
+        check(lib.kccot_row_norms_f64(ptr(real_l), ptr(fake_l), Bl, K, ptr(out), ws, wsb, stream_of(real_l)), "row_norms")
+        return out
+
+    @staticmethod
+    def cost3_rows(real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, row_count, norms=None):
+        """Row blocks [3, row_count, B] of (xy, xx, yy): on the matrix pipe when the gathered `norms` [B,3] are given
+        (kccot_pairwise_cost3_rows_gram_f32), else one launch of the direct-difference kernel
+        (kccot_pairwise_cost3_rows_f32)."""
         B, K = real.shape
         T, J = h_fake.shape[1], h_fake.shape[2]
         out = _lib.empty((3, row_count, B), torch.float32, real.device)
+        if norms is not None:
+            ws, wsb = workspace(lib.kccot_pairwise_cost3_rows_gram_workspace_bytes(row_count, B, K), real)
+            check(lib.kccot_pairwise_cost3_rows_gram_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
+                                                         ptr(m_fake), T, J, row_begin, row_count, ptr(norms.contiguous()),
+                                                         ptr(out), ws, wsb, stream_of(real)), "pairwise_cost3_rows_gram")
+            return out
         ws, wsb = workspace(lib.kccot_pairwise_cost3_rows_workspace_bytes(row_count, B, K), real)
         check(lib.kccot_pairwise_cost3_rows_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
                                                 ptr(m_fake), T, J, row_begin, row_count, ptr(out), ws, wsb,
@@ -320,6 +346,12 @@ class _ShardedLoss(torch.autograd.Function):
     def forward(ctx, real_l, fake_l, h_fake_l, h_real_l, m_real_l, m_fake_l, sc, eps, L, group, ops):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         Bl = real_l.shape[0]
+        # B > 64 on the HIP ops: the row block runs on the matrix pipe and needs x.x, e.e, x.e of every sample -- each rank
+        # computes its own rows' from its local shard and the 24 bytes per sample are gathered ahead of the videos
+        norms = None
+        if (hasattr(ops, "row_norms") and not ops.replicate_costs(Bl * world, real_l.shape[1])
+                and ops.rows_gram_supported(Bl, Bl * world, real_l.shape[1]) and os.environ.get("KCCOT_DIST_ROWS") != "direct"):
+            norms = all_gather_cat(ops.row_norms(real_l, fake_l), group)
         real = all_gather_cat(real_l, group)
         fake = all_gather_cat(fake_l, group)
         # the four [Bl,T,J] feature shards travel as one message
@@ -329,7 +361,9 @@ class _ShardedLoss(torch.autograd.Function):
             C3 = ops.cost3_full(real, fake, h_fake, h_real, m_real, m_fake, sc)     # small batch: replicated assembly
         else:
             # row blocks of the three cost matrices (gan_utils.py:221-223)
-            if hasattr(ops, "cost3_rows"):       # one launch for the three row blocks
+            if norms is not None:                # the Gram row block on the matrix pipe
+                blk = ops.cost3_rows(real, fake, h_fake, h_real, m_real, m_fake, sc, rank * Bl, Bl, norms)
+            elif hasattr(ops, "cost3_rows"):     # one launch for the three row blocks
                 blk = ops.cost3_rows(real, fake, h_fake, h_real, m_real, m_fake, sc, rank * Bl, Bl)
             else:
                 blk = torch.stack([ops.cost_rows(real_l, fake, h_fake_l, m_real, sc),

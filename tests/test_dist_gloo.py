@@ -139,13 +139,16 @@ def test_data_parallel_trainer_keeps_replicas_identical(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("protocol", ["auto", "gather"])
+@pytest.mark.parametrize("protocol", ["auto", "gather", "gather_direct"])
 def test_sharded_hip_batch_128(protocol, tmp_path):
-    """Two ranks at B = 128 (the tiled Gram path): `auto` picks the contraction-sharded protocol above 64 samples,
-    `gather` keeps the row blocks on the direct kernel; both against the single-GPU loss and gradients."""
+    """Two ranks at B = 128 (64 samples each): `auto` picks the contraction-sharded protocol above 64 samples; `gather`
+    builds the row blocks on the matrix pipe (Gram row block + all-gathered row norms, csrc/cost_rows.hip);
+    `gather_direct` keeps them on the direct-difference kernel (KCCOT_DIST_ROWS=direct); all against the single-GPU loss
+    and gradients."""
     from kccotgan_amd import gan_utils as G
     shape, seed, regime = "deci128", 0, "near"
-    res = launch(2, shape, seed, regime, "cuda:0", "hip", tmp_path, env={"KCCOT_DIST_PROTOCOL": protocol})
+    env = {"KCCOT_DIST_PROTOCOL": "gather", "KCCOT_DIST_ROWS": "direct"} if protocol == "gather_direct" else {"KCCOT_DIST_PROTOCOL": protocol}
+    res = launch(2, shape, seed, regime, "cuda:0", "hip", tmp_path, env=env)
     inp = cases.gen_inputs(shape, seed, regime)
     t = {k: torch.from_numpy(v).to("cuda:0") for k, v in inp.items()}
     for k in NAMES:

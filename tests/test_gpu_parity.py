@@ -482,6 +482,43 @@ def test_tiled_gram_128_row_tiles_with_materialised_difference_rows(G, L):
         np.testing.assert_allclose(np.diag(got[k]), np.diag(ref[k]), rtol=2e-5, atol=1e-7, err_msg=tag + " diagonal")
 
 
+@pytest.mark.parametrize("B,G_,K", [(128, 4, 2560), (256, 8, 2560 + 36), (512, 8, 3072), (384, 6, 1536 + 4), (128, 2, 1024)])
+def test_rows_gram_row_blocks_against_the_direct_kernel_and_the_oracle(G, L, B, G_, K):
+    """The batch-sharded rank's row block on the matrix pipe (cost_rows.hip: Gram row block [X_I ; E_I][X ; E]^T + gathered
+    row norms) for 32 and 64 rows per rank, column panels of X rows, E rows and the mixed panel of B % 256 == 128, K a multiple
+    of 32 and not: every rank's block against the direct-difference kernel and the fp64 oracle, the C_xy diagonal entries
+    (sample against its own fake) relatively, and with norms = NULL (the call computes them itself)."""
+    from kccotgan_amd.dist import HipOps as H
+    real, fake, f = _tile_inputs(B, K, 5000 + B + K)
+    m = B // G_
+    assert H.rows_gram_supported(m, B, K)
+    norms = torch.cat([H.row_norms(real[r * m:(r + 1) * m], fake[r * m:(r + 1) * m]) for r in range(G_)])   # as the all-gather delivers
+    ref = _cost3_oracle(real, fake, f)
+    x64, y64 = real.double().cpu().numpy(), fake.double().cpu().numpy()
+    e64 = y64 - x64
+    np.testing.assert_allclose(norms.cpu().numpy(), np.stack([(x64 * x64).sum(1), (e64 * e64).sum(1), (x64 * e64).sum(1)], 1),
+                               rtol=2e-6, atol=1e-4)
+    for r in sorted({0, G_ // 2, G_ - 1}):
+        got = H.cost3_rows(real, fake, f[0], f[1], f[2], f[3], cases.SC, r * m, m, norms).cpu().numpy()
+        direct = H.cost3_rows(real, fake, f[0], f[1], f[2], f[3], cases.SC, r * m, m).cpu().numpy()
+        for k, tag in enumerate(("xy", "xx", "yy")):
+            want = ref[k][r * m:(r + 1) * m]
+            tol = 1e-5 * np.abs(ref[k]).max()
+            np.testing.assert_allclose(got[k], want, rtol=0, atol=tol, err_msg="gram %s rank %d" % (tag, r))
+            np.testing.assert_allclose(direct[k], want, rtol=0, atol=tol, err_msg="direct %s rank %d" % (tag, r))
+        i = np.arange(m)
+        np.testing.assert_allclose(got[0][i, r * m + i], ref[0][r * m + i, r * m + i], rtol=2e-5, atol=1e-7)
+        assert np.all(got[1][i, r * m + i] == direct[1][i, r * m + i])          # x == y: exactly the causal term
+    own = torch.empty((3, m, B), device=DEV)
+    ws = torch.empty(int(L.lib.kccot_pairwise_cost3_rows_gram_workspace_bytes(m, B, K)), dtype=torch.uint8, device=DEV)
+    L.check(L.lib.kccot_pairwise_cost3_rows_gram_f32(L.ptr(real), L.ptr(fake), B, K, cases.SC, L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]),
+                                                     L.ptr(f[3]), f[0].shape[1], f[0].shape[2], m, m, None, L.ptr(own),
+                                                     ws.data_ptr(), ws.numel(), None), "rows_gram")
+    np.testing.assert_allclose(own.cpu().numpy(), H.cost3_rows(real, fake, f[0], f[1], f[2], f[3], cases.SC, m, m, norms).cpu().numpy(),
+                               rtol=0, atol=2e-6 * np.abs(ref[0]).max())
+    assert not H.rows_gram_supported(16, B, K) and not H.rows_gram_supported(m, B + 64, K)
+
+
 @pytest.mark.parametrize("B,K", [(64, 4100), (37, 3076), (7, 256), (64, 64 * 300 + 36), (33, 128)])
 def test_gram_producers_on_ragged_shapes(G, L, B, K):
     """The producers of gram128_partial_x3ws keep two stages of UNCONDITIONAL (clamped) loads in flight and zero the
