@@ -86,6 +86,11 @@ const char* kccot_last_error(void);
  *                                      streaming kernels (radius 3 / 4)
  *   smooth_generic            0        1: the any-length / any-alignment streaming kernels even where the register-line ones apply
  *   smooth_fused_tw           1        0: T and W stage of the 3-D smoothing as two launches instead of one
+ *   smooth_bwd_fold           1        0: the smoothing backward computes the normalisation's two sums in a pass of its own
+ *                                      first; 1: from 4 M elements (temporal) / 32 M (3-D) on its first adjoint stage gathers
+ *                                      them and a sparse fix-up applies them (two tensor reads fewer; data with > 32 arg-max
+ *                                      elements -- saturated still regions -- then pays the two-pass chain on top, decided on
+ *                                      the device: set 0 for such data); 2: at every size (tests)
  * ------------------------------------------------------------------------------------------- */
 int kccot_set_option(const char* name, int value);
 int kccot_get_option(const char* name, int* value);

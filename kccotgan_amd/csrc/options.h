@@ -20,6 +20,7 @@ enum Option {
     OPT_SMOOTH_STREAM,           // "smooth_stream"
     OPT_SMOOTH_GENERIC,          // "smooth_generic"
     OPT_SMOOTH_FUSED_TW,         // "smooth_fused_tw"
+    OPT_SMOOTH_BWD_FOLD,         // "smooth_bwd_fold"
     OPT_COUNT
 };
 

@@ -347,7 +347,34 @@ __global__ __launch_bounds__(NT) void smooth_plane(PlaneArgs a) {
 // Adjoint weights: w_k(p) = w[k] + [p >= 1] w[-2p-k] + [p <= L-2] w[2(L-1)-2p-k] (taps outside -R..R
 // are zero), sources outside [0,L) do not exist; the head fold is known at compile time, the tail
 // fold depends on d = L-1-p and is chosen with scalar selects.
-enum { WALK_MAX = 0, WALK_WRITE = 1, WALK_RAW = 2, WALK_ADJ = 3, WALK_ADJX = 4, WALK_RAW_TW = 6 };
+enum { WALK_MAX = 0, WALK_WRITE = 1, WALK_RAW = 2, WALK_ADJ = 3, WALK_ADJX = 4, WALK_ADJS = 5, WALK_RAW_TW = 6 };
+// WALK_ADJS (round 3): the first adjoint stage WITHOUT the arg-max correction, x = g / max, which ALSO gathers what that
+// correction needs while it streams gout and the forward output anyway: one TieRec per workgroup = its sum of g * out,
+// its number of elements with out == 1 and the positions of the first TIE_PER_WG of them.  The adjoint is linear, so
+// A^T (g / max - corr [out == 1]) = A^T (g / max) - corr A^T [out == 1]:  the second term touches the (2R+1)^axes
+// neighbours of each arg-max element and is subtracted afterwards by maxnorm_bwd_fixup -- the separate pass over gout
+// and out that computed the two sums first (two tensor reads of the five of the temporal backward) is gone.  No global
+// atomics and nothing to zero in front of the launch: every workgroup writes its own record.
+constexpr int SMOOTH_MAX_TIES = 32;    // arg-max elements the sparse fix-up handles; more -> the dense fallback (on the device)
+constexpr int TIE_PER_WG = 4;
+struct TieRec { double dot; long long idx[TIE_PER_WG]; int ties; int pad; };
+
+struct TieNote {                       // LDS side of one workgroup's record (workgroups of 256 threads)
+    double part[4]; long long idx[TIE_PER_WG]; int n;
+    __device__ __forceinline__ void clear() { if (threadIdx.x == 0) n = 0; __syncthreads(); }
+    __device__ __forceinline__ void add(long long e) { const int slot = atomicAdd(&n, 1); if (slot < TIE_PER_WG) idx[slot] = e; }
+    // `dot` = the thread's sum of g * out, kept in fp64: the sum cancels (g has both signs), and the correction it feeds
+    // is the largest entry of the gradient
+    __device__ __forceinline__ void store(TieRec* rec, double dot) {
+        dot = wave_sum_d(dot);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = dot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            rec->dot = (part[0] + part[1]) + (part[2] + part[3]); rec->ties = n; rec->pad = 0;
+            for (int i = 0; i < TIE_PER_WG; ++i) rec->idx[i] = idx[i];
+        }
+    }
+};
 
 // WALK_RAW_TW (C == 1, four consecutive w per thread, W/4 a power of two <= 64): the T walk with the W stencil of
 // smooth_w1 applied to every T-smoothed piece before it is stored -- the left / right neighbour pieces of a row are the
@@ -372,6 +399,9 @@ struct WalkArgs {
     const float* mx;       // WALK_WRITE / WALK_ADJX: device scalar, the tensor maximum
     const float* res;      // WALK_ADJX: {sum gout*out, #ties}
     float* mx_out;         // WALK_WRITE with nblk > 0: the tensor maximum is written here
+    TieRec* ties;          // WALK_ADJS: one record per workgroup
+    const int* run_if;     // WALK_ADJ / WALK_ADJX: non-null -> the launch does nothing unless *run_if != 0 (the backward's
+                           // dense chain, decided on the device by maxnorm_bwd_fixup)
     int nblk;              // WALK_WRITE: > 0 = reduce blockmax[0, nblk) (the preceding WALK_MAX launch's) instead of reading mx
     int L;                 // axis length
     int64_t S;             // axis stride in floats
@@ -390,8 +420,9 @@ template <int VW, typename V> __device__ __forceinline__ float& vat(V& v, int c)
 template <int R, int LMAX, int VW, int MODE>
 __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
     typedef typename WalkVec<VW>::type V;
-    constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX;
+    constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX || MODE == WALK_ADJS;
     __shared__ float red[16];
+    if ((MODE == WALK_ADJ || MODE == WALK_ADJX) && a.run_if && *a.run_if == 0) return;
     const int L = a.L;
     const int64_t S = a.S;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -400,8 +431,11 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
     const int64_t off = (g / a.inner) * L * S + (g % a.inner) * VW;
     const float* src = a.in + off;
     float m = 1.f, corr = 0.f;
-    if ((MODE == WALK_WRITE && a.nblk <= 0) || MODE == WALK_ADJX) m = a.mx[0];
+    if ((MODE == WALK_WRITE && a.nblk <= 0) || MODE == WALK_ADJX || MODE == WALK_ADJS) m = a.mx[0];
     if (MODE == WALK_ADJX) corr = a.res[1] > 0.f ? a.res[0] / (m * a.res[1]) : 0.f;
+    double sdot = 0.0;                  // WALK_ADJS
+    __shared__ TieNote note;
+    if (MODE == WALK_ADJS) note.clear();
     V x[LMAX];
 #pragma unroll
     for (int p = 0; p < LMAX; ++p) {    // addresses clamped, never predicated: all loads issue back to back
@@ -411,6 +445,18 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
             V of = *reinterpret_cast<const V*>(a.out_fwd + off + o);
 #pragma unroll
             for (int c = 0; c < VW; ++c) vat<VW>(x[p], c) = vat<VW>(x[p], c) / m - (vat<VW>(of, c) == 1.0f ? corr : 0.f);
+        }
+        if (MODE == WALK_ADJS) {
+            V of = *reinterpret_cast<const V*>(a.out_fwd + off + o);
+#pragma unroll
+            for (int c = 0; c < VW; ++c) {
+                const float gg = vat<VW>(x[p], c), oo = vat<VW>(of, c);
+                if (ok && p < L) {
+                    sdot = fma((double)gg, (double)oo, sdot);
+                    if (oo == 1.0f) note.add((long long)(off + o + c));
+                }
+                vat<VW>(x[p], c) = gg / m;
+            }
         }
     }
     if (MODE == WALK_WRITE && a.nblk > 0) {
@@ -510,6 +556,7 @@ __global__ __launch_bounds__(256) void smooth_walk(WalkArgs a) {
         const float bm = block_max(ok ? vmax : -FLT_MAX, red);
         if (threadIdx.x == 0) a.blockmax[blockIdx.x] = bm;
     }
+    if (MODE == WALK_ADJS) note.store(a.ties + blockIdx.x, sdot);
 }
 
 // ---- W axis, C == 1: the axis is the contiguous one ------------------------------------------------
@@ -580,8 +627,9 @@ __global__ __launch_bounds__(256) void smooth_w1(const float* __restrict__ in, f
 template <int R, int VW, int MODE>
 __global__ __launch_bounds__(256) void smooth_roll(WalkArgs a) {
     typedef typename WalkVec<VW>::type V;
-    constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX;
+    constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX || MODE == WALK_ADJS;
     constexpr int U = 8, NW = 2 * R + 1;
+    if ((MODE == WALK_ADJ || MODE == WALK_ADJX) && a.run_if && *a.run_if == 0) return;
     extern __shared__ float roll_wt[];      // ADJ: L x NW weights
     __shared__ float red[16];
     const int L = a.L;
@@ -600,8 +648,11 @@ __global__ __launch_bounds__(256) void smooth_roll(WalkArgs a) {
     const int64_t off = (g / a.inner) * L * S + (g % a.inner) * VW;
     const float* src = a.in + off;
     float m = 1.f, corr = 0.f;
-    if ((MODE == WALK_WRITE && a.nblk <= 0) || MODE == WALK_ADJX) m = a.mx[0];
+    if ((MODE == WALK_WRITE && a.nblk <= 0) || MODE == WALK_ADJX || MODE == WALK_ADJS) m = a.mx[0];
     if (MODE == WALK_ADJX) corr = a.res[1] > 0.f ? a.res[0] / (m * a.res[1]) : 0.f;
+    double sdot = 0.0;                  // WALK_ADJS
+    __shared__ TieNote note;
+    if (MODE == WALK_ADJS) note.clear();
     V zero;
 #pragma unroll
     for (int c = 0; c < VW; ++c) vat<VW>(zero, c) = 0.f;
@@ -615,6 +666,18 @@ __global__ __launch_bounds__(256) void smooth_roll(WalkArgs a) {
             const V of = *reinterpret_cast<const V*>(a.out_fwd + off + (int64_t)qq * S);
 #pragma unroll
             for (int c = 0; c < VW; ++c) vat<VW>(v, c) = vat<VW>(v, c) / m - (vat<VW>(const_cast<V&>(of), c) == 1.0f ? corr : 0.f);
+        }
+        if (MODE == WALK_ADJS) {        // every position inside [0, L) is fetched exactly once (no reflection in the adjoint)
+            const V of = *reinterpret_cast<const V*>(a.out_fwd + off + (int64_t)qq * S);
+#pragma unroll
+            for (int c = 0; c < VW; ++c) {
+                const float gg = vat<VW>(v, c), oo = vat<VW>(const_cast<V&>(of), c);
+                if (ok && inside) {
+                    sdot = fma((double)gg, (double)oo, sdot);
+                    if (oo == 1.0f) note.add((long long)(off + (int64_t)qq * S + c));
+                }
+                vat<VW>(v, c) = gg / m;
+            }
         }
         if (ADJ) v = inside ? v : zero;
         return v;
@@ -675,6 +738,7 @@ __global__ __launch_bounds__(256) void smooth_roll(WalkArgs a) {
         const float bm = block_max(ok ? vmax : -FLT_MAX, red);
         if (threadIdx.x == 0) a.blockmax[blockIdx.x] = bm;
     }
+    if (MODE == WALK_ADJS) note.store(a.ties + blockIdx.x, sdot);
 }
 
 // smooth_wrow: the contiguous axis W with C interleaved channels.  A workgroup stages `rpw` rows of W*C floats in LDS
@@ -1006,6 +1070,7 @@ static int launch_walk(int mode, WalkArgs wa, int radius, int64_t numel, WalkPla
         case WALK_RAW: KCCOT_WALK_MODE(WALK_RAW); break;
         case WALK_ADJ: KCCOT_WALK_MODE(WALK_ADJ); break;
         case WALK_RAW_TW: KCCOT_WALK_MODE(WALK_RAW_TW); break;
+        case WALK_ADJS: KCCOT_WALK_MODE(WALK_ADJS); break;
         default: KCCOT_WALK_MODE(WALK_ADJX); break;
     }
 #undef KCCOT_WALK_MODE
@@ -1015,7 +1080,7 @@ static int launch_walk(int mode, WalkArgs wa, int radius, int64_t numel, WalkPla
 template <int R, int MODE>
 static void launch_roll_r(const WalkArgs& wa, int vw, hipStream_t st) {
     const dim3 grid((unsigned)((wa.ncols + 255) / 256));
-    constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX;
+    constexpr bool ADJ = MODE == WALK_ADJ || MODE == WALK_ADJX || MODE == WALK_ADJS;
     const size_t lds = ADJ ? (size_t)wa.L * (2 * R + 1) * sizeof(float) : 0;
     if (vw == 4) hipLaunchKernelGGL((smooth_roll<R, 4, MODE>), grid, dim3(256), lds, st, wa);
     else if (vw == 2) hipLaunchKernelGGL((smooth_roll<R, 2, MODE>), grid, dim3(256), lds, st, wa);
@@ -1032,6 +1097,7 @@ static int launch_roll(int mode, WalkArgs wa, int radius, int64_t numel, int vw,
         case WALK_RAW: KCCOT_ROLL_MODE(WALK_RAW); break;
         case WALK_ADJ: KCCOT_ROLL_MODE(WALK_ADJ); break;
         case WALK_ADJX: KCCOT_ROLL_MODE(WALK_ADJX); break;
+        case WALK_ADJS: KCCOT_ROLL_MODE(WALK_ADJS); break;
         default: return fail(KCCOT_EINVAL, "smooth: mode %d has no rolling form", mode);
     }
 #undef KCCOT_ROLL_MODE
@@ -1080,6 +1146,115 @@ __global__ __launch_bounds__(256) void maxnorm_bwd_partial_v4(const float* __res
     if (threadIdx.x == 0) { pdot[blockIdx.x] = ds; pcnt[blockIdx.x] = cs; }
 }
 
+// ---- the sparse half of the folded backward (WALK_ADJS) ----------------------------------------------------------------
+// One workgroup.  Adds the workgroups' records up (res[0] = sum g * out in fp64, res[1] = number of arg-max elements),
+// and, when there are at most SMOOTH_MAX_TIES of them (one, for any real video), subtracts corr * A^T [out == 1] from din:
+// per arg-max element the (2R+1)^axes REFLECT neighbours, one thread per tap combination, taps that fold onto the same
+// position merged first (one writer per position), the elements in index order one after the other: deterministic.
+// More arg-max elements than that (a saturated still image: a whole region ties) -> *dense = 1 and nothing is touched;
+// the guarded dense chain behind this launch (the round-2 kernels with WalkArgs::run_if) then recomputes din the plain way.
+struct FixupArgs {
+    const TieRec* ties; int nrec;
+    const float* mx; float* res; int* dense; float* din;
+    int len[3]; long long stride[3]; int na;   // the smoothed axes
+    Taps tp;
+};
+
+__global__ __launch_bounds__(1024) void maxnorm_bwd_fixup(FixupArgs a) {
+    __shared__ double dsum[16];
+    __shared__ int isum[16];
+    __shared__ int nlist, overflow;
+    __shared__ long long list[SMOOTH_MAX_TIES];
+    if (threadIdx.x == 0) { nlist = 0; overflow = 0; }
+    __syncthreads();
+    const float m = a.mx[0];            // early: its latency hides under the scan
+    double d = 0.0;
+    int c = 0;
+    for (int i = threadIdx.x; i < a.nrec; i += 1024) {
+        const TieRec r = a.ties[i];
+        d += r.dot;
+        c += r.ties;
+        if (r.ties > TIE_PER_WG) overflow = 1;
+        for (int j = 0; j < r.ties && j < TIE_PER_WG; ++j) {
+            const int slot = atomicAdd(&nlist, 1);
+            if (slot < SMOOTH_MAX_TIES) list[slot] = r.idx[j];
+        }
+    }
+    d = wave_sum_d(d);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) { dsum[threadIdx.x >> 6] = d; isum[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    d = 0.0; c = 0;
+    for (int w = 0; w < 16; ++w) { d += dsum[w]; c += isum[w]; }
+    const bool dense = overflow != 0 || c > SMOOTH_MAX_TIES;
+    if (threadIdx.x == 0) { a.res[0] = (float)d; a.res[1] = (float)c; *a.dense = dense ? 1 : 0; }
+    if (dense || c == 0) return;
+    if (threadIdx.x == 0)               // index order (the records arrive in any order)
+        for (int i = 1; i < c; ++i) {
+            const long long v = list[i];
+            int j = i - 1;
+            for (; j >= 0 && list[j] > v; --j) list[j + 1] = list[j];
+            list[j + 1] = v;
+        }
+    __syncthreads();
+    const float corr = (float)d / (m * (float)c);
+    const int nt = 2 * a.tp.r + 1;
+    int combos = 1;
+    for (int x = 0; x < a.na; ++x) combos *= nt;
+    for (int t = 0; t < c; ++t) {
+        const long long e = list[t];
+        for (int q = threadIdx.x; q < combos; q += 1024) {
+            int rem = q;
+            long long target = e;
+            float w = 1.f;
+            bool owner = true;
+            for (int x = 0; x < a.na; ++x) {
+                const int k = rem % nt;
+                rem /= nt;
+                const int p0 = (int)((e / a.stride[x]) % a.len[x]);
+                const int pos = reflect(p0 + k - a.tp.r, a.len[x]);
+                float wx = 0.f;
+                for (int k2 = 0; k2 < nt; ++k2)
+                    if (reflect(p0 + k2 - a.tp.r, a.len[x]) == pos) {
+                        if (k2 < k) owner = false;
+                        wx += a.tp.w[k2];
+                    }
+                w *= wx;
+                target += (long long)(pos - p0) * a.stride[x];
+            }
+            if (owner) a.din[target] -= corr * w;
+        }
+        __syncthreads();
+    }
+}
+
+// The W stage of the backward's dense chain (its H and T stages are the walks themselves, WalkArgs::run_if): a no-op
+// unless *run_if != 0 -- decided on the device, without a host round trip.  A small fixed grid with a grid-stride loop: a
+// launch that does nothing must cost nothing (one workgroup per 256 elements takes the dispatcher longer to start and
+// retire than the folded kernels run).  W is the contiguous axis: neighbouring threads read neighbouring addresses.
+__global__ __launch_bounds__(256) void conv_axis_adjoint_if(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                            int len, int64_t stride, Taps tp,
+                                                            const int* __restrict__ run_if) {
+    if (*run_if == 0) return;
+    const int r = tp.r;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int p = (int)((e / stride) % len);
+        const float* base = in + (e - (int64_t)p * stride);
+        float acc = 0.f;
+        for (int d = -r; d <= r; ++d) {
+            const float w = tp.w[d + r];
+            int t = p - d;
+            if (t >= 0 && t < len) acc = fmaf(w, base[(int64_t)t * stride], acc);
+            t = -p - d;
+            if (p >= 1 && t >= 0 && t < len) acc = fmaf(w, base[(int64_t)t * stride], acc);
+            t = 2 * (len - 1) - p - d;
+            if (p <= len - 2 && t >= 0 && t < len) acc = fmaf(w, base[(int64_t)t * stride], acc);
+        }
+        out[e] = acc;
+    }
+}
+
 static bool plane_eligible(int T, int W, int C, int radius, int naxes) {
     return naxes > 0 && (radius == 3 || radius == 4) && (int64_t)T * W * C <= 4096;
 }
@@ -1125,8 +1300,10 @@ extern "C" size_t kccot_smooth_workspace_bytes(int B, int H, int T, int W, int C
     if (B <= 0 || H <= 0 || T <= 0 || W <= 0 || C <= 0) return 0;
     const size_t n = (size_t)B * H * T * W * C;
     const size_t nb = (n + 255) / 256;
-    // one tensor-sized ping-pong buffer + two per-block reduction arrays + 4 scalars
-    return align_up(n * sizeof(float), 256) + 2 * align_up(nb * sizeof(float), 256) + 256;
+    // one tensor-sized ping-pong buffer + two per-block reduction arrays + scalars + the backward's per-workgroup tie
+    // records (a line kernel's workgroup covers >= 256 lines of >= 4 elements)
+    return align_up(n * sizeof(float), 256) + 2 * align_up(nb * sizeof(float), 256) + 256 +
+           align_up((n / 1024 + 2) * sizeof(TieRec), 256);
 }
 
 static int smooth_check(const char* who, const void* a, const void* b, int B, int H, int T, int W, int C, float sigma,
@@ -1304,9 +1481,36 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
     float* ds = (na % 2 == 0) ? din : tmp;
     const bool wide = (n % 4 == 0) && ((uintptr_t)gout % 16 == 0) && ((uintptr_t)out % 16 == 0) && nb >= 2048;
     const int64_t nparts = wide ? 2048 : nb;
+    float* scal = reinterpret_cast<float*>(p + 2 * align_up((size_t)nb * sizeof(float), 256));   // workspace scalars {dot, ties, .., .., 1, 0, 0, dense}
+    TieRec* recs = reinterpret_cast<TieRec*>(p + 2 * align_up((size_t)nb * sizeof(float), 256) + 256);
+    const unsigned axes = flags & (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W);
+    // The streaming chains (temporal only / all three axes, radius 3 or 4).  Decided in front of the statistics: with the
+    // option "smooth_bwd_fold" the chain's first stage gathers them itself (WALK_ADJS) and the pass below is skipped.
+    const int64_t WC = (int64_t)W * C;
+    const bool three = axes != KCCOT_SMOOTH_T;
+    bool chain = (radius == 3 || radius == 4) && opt(OPT_SMOOTH_STREAM) && !stats_only &&
+                 (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W));
+    AxisPlan ph{AXIS_LINE, WalkPlan{1, 32}, 1}, pt{AXIS_NONE, WalkPlan{0, 0}, 0};
+    bool w1 = false, wplane = false, wrow = false, twp = false;
+    if (chain) {
+        // adjoint stages in reverse order; the first one also applies the adjoint of the max-normalisation
+        if (three) ph = axis_plan(H, (int64_t)T * WC, true, true, radius, gout, out, din);
+        pt = axis_plan(T, WC, !three, true, radius, three ? (const void*)tmp : (const void*)gout, out, din);
+        w1 = three && w1_eligible(W, C, radius, din, tmp) && !smooth_generic();
+        wplane = three && !w1 && plane_eligible(T, W, C, radius, 1) && !smooth_generic();
+        wrow = three && !w1 && !wplane && wrow_eligible(W, C, radius);
+        twp = three && tw_plane_eligible(T, W, C, radius, true, tmp, din);
+        chain = pt.kind != AXIS_NONE && ph.kind != AXIS_NONE && (!three || w1 || wplane || wrow || twp);
+    }
+    // Folding trades two tensor reads for two (temporal) / four (3-D) more launches of ~5 us each behind the chain (the
+    // fix-up and the guarded dense chain, dependent launches on one stream).  Measured: temporal 17.7 -> 22.0 us at 2 M
+    // elements, 33.9 -> 32.8 us at 7.9 M, 350 -> 254 us at 94 M; 3-D 37.8 -> 61.1 us at 2 M, 65.4 -> 79.0 us at 7.9 M,
+    // 684 -> 635 us at 94 M.  Option value 1 folds from 4 M (temporal) / 32 M (3-D) elements on, 2 always (tests), 0 never.
+    const int fold_opt = opt(OPT_SMOOTH_BWD_FOLD);
+    const bool fold = chain && !stats_in && (fold_opt == 2 || (fold_opt == 1 && n >= (three ? (int64_t)1 << 25 : (int64_t)1 << 22)));
     if (stats_in) {
         res = stats_ext;                                       // the global sums: every kernel below reads res[0], res[1]
-    } else {
+    } else if (!fold) {
         if (stats_only) res = stats_ext;
         if (wide) hipLaunchKernelGGL(maxnorm_bwd_partial_v4, dim3(2048), dim3(256), 0, st, gout, out, n / 4, pdot, pcnt);
         else hipLaunchKernelGGL(maxnorm_bwd_partial, dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, pdot, pcnt);
@@ -1315,30 +1519,50 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
         if ((rc = launch_status("maxnorm_bwd_combine"))) return rc;
         if (stats_only) return 0;
     }
-    float* scal = reinterpret_cast<float*>(p + 2 * align_up((size_t)nb * sizeof(float), 256));   // workspace scalars {.., .., .., .., 1, 0, 0}
-    const unsigned axes = flags & (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W);
-    if ((radius == 3 || radius == 4) && opt(OPT_SMOOTH_STREAM) &&
-        (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W))) {
-        const int64_t WC = (int64_t)W * C;
-        const bool three = axes != KCCOT_SMOOTH_T;
-        // adjoint stages in reverse order; the first one also applies the adjoint of the max-normalisation
-        const AxisPlan ph = three ? axis_plan(H, (int64_t)T * WC, true, true, radius, gout, out, din) : AxisPlan{AXIS_LINE, WalkPlan{1, 32}, 1};
-        const AxisPlan pt = axis_plan(T, WC, !three, true, radius, three ? (const void*)tmp : (const void*)gout, out, din);
-        const bool w1 = three && w1_eligible(W, C, radius, din, tmp) && !smooth_generic();
-        const bool wplane = three && !w1 && plane_eligible(T, W, C, radius, 1) && !smooth_generic();
-        const bool wrow = three && !w1 && !wplane && wrow_eligible(W, C, radius);
-        const bool twp = three && tw_plane_eligible(T, W, C, radius, true, tmp, din);
-        if (pt.kind != AXIS_NONE && ph.kind != AXIS_NONE && (!three || w1 || wplane || wrow || twp)) {
+    if (chain) {
+        {
             WalkArgs wa{};
-            wa.tp = tp; wa.out_fwd = out; wa.mx = max_in; wa.res = res;
+            wa.tp = tp; wa.out_fwd = out; wa.mx = max_in; wa.res = res; wa.ties = recs;
+            const int first = fold ? WALK_ADJS : WALK_ADJX;
+            const AxisPlan& p1 = three ? ph : pt;               // the stage that reads gout and the forward output
+            const int nrec = (int)((n / (three ? H : T) / p1.vw + 255) / 256);
+            // what follows the last stage when the statistics were folded into the first: the sparse fix-up, then the
+            // dense chain that only runs when the fix-up found too many arg-max elements
+            auto finish = [&]() -> int {
+                if (!fold) return 0;
+                int* dense = reinterpret_cast<int*>(scal + 7);
+                FixupArgs fa{};
+                fa.ties = recs; fa.nrec = nrec; fa.mx = max_in; fa.res = res; fa.dense = dense; fa.din = din; fa.na = na; fa.tp = tp;
+                for (int i = 0; i < na; ++i) { fa.len[i] = ax[i].len; fa.stride[i] = ax[i].stride; }
+                hipLaunchKernelGGL(maxnorm_bwd_fixup, dim3(1), dim3(1024), 0, st, fa);
+                int rc2 = launch_status("maxnorm_bwd_fixup");
+                if (rc2) return rc2;
+                // the round-2 chain with the sums the fix-up has just written: H^T (+ normalisation adjoint) gout -> din,
+                // W^T din -> tmp, T^T tmp -> din;  temporal only: T^T (+ normalisation adjoint) gout -> din
+                WalkArgs wd{};
+                wd.tp = tp; wd.out_fwd = out; wd.mx = max_in; wd.res = res; wd.run_if = dense;
+                wd.in = gout; wd.out = din; wd.L = three ? H : T; wd.S = three ? (int64_t)T * WC : WC;
+                if ((rc2 = launch_axis(WALK_ADJX, wd, radius, n, p1, st))) return rc2;
+                if (!three) return 0;
+                hipLaunchKernelGGL(conv_axis_adjoint_if, dim3((unsigned)std::min<int64_t>(nb, 2048)), dim3(256), 0, st,
+                                   (const float*)din, tmp, n, W, (int64_t)C, tp, (const int*)dense);
+                if ((rc2 = launch_status("conv_axis_adjoint_if"))) return rc2;
+                wd.in = tmp; wd.out = din; wd.L = T; wd.S = WC;
+                if ((rc2 = launch_axis(WALK_ADJ, wd, radius, n, pt, st))) return rc2;
+                return 0;
+            };
             if (!three) {
                 wa.in = gout; wa.out = din; wa.L = T; wa.S = WC;
-                return launch_axis(WALK_ADJX, wa, radius, n, pt, st);
+                if ((rc = launch_axis(first, wa, radius, n, pt, st))) return rc;
+                return finish();
             }
             // H^T (+ normalisation adjoint): gout -> din;  W^T: din -> tmp;  T^T: tmp -> din
             wa.in = gout; wa.out = twp ? tmp : din; wa.L = H; wa.S = (int64_t)T * WC;
-            if ((rc = launch_axis(WALK_ADJX, wa, radius, n, ph, st))) return rc;
-            if (twp) return launch_tw_plane(tmp, din, n, T, W, C, radius, true, tp, st);   // W^T and T^T in one pass: tmp -> din
+            if ((rc = launch_axis(first, wa, radius, n, ph, st))) return rc;
+            if (twp) {                                              // W^T and T^T in one pass: tmp -> din
+                if ((rc = launch_tw_plane(tmp, din, n, T, W, C, radius, true, tp, st))) return rc;
+                return finish();
+            }
             if (w1) {
                 if ((rc = launch_w1(din, tmp, n, W, radius, true, tp, st))) return rc;
             } else if (wrow) {
@@ -1355,7 +1579,8 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
                 if ((rc = launch_plane(pa, radius, true, dim3((H + pa.hseg - 1) / pa.hseg, B), st))) return rc;
             }
             wa.in = tmp; wa.out = din; wa.L = T; wa.S = WC;
-            return launch_axis(WALK_ADJ, wa, radius, n, pt, st);
+            if ((rc = launch_axis(WALK_ADJ, wa, radius, n, pt, st))) return rc;
+            return finish();
         }
     }
     hipLaunchKernelGGL(maxnorm_bwd_apply, dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, max_in, (const float*)res, ds);

@@ -316,3 +316,74 @@ def test_full_size_smoothing_at_the_large_baseline_shapes(shape):
         torch.cuda.synchronize()
         assert bool(torch.isfinite(d).all())
         del o, d, gr
+
+
+def _bwd(g, out, mx, radius, axes, sigma=2.1):
+    """kccot_smooth_bwd_f32 on a given (gout, forward output, maximum): the forward output is an INPUT of the backward, so
+    a test can plant any number of arg-max elements in it."""
+    import torch
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, check, ptr, stream_of, workspace
+    B, H, T, W, C = out.shape
+    din = torch.empty_like(out)
+    ws, wsb = workspace(lib.kccot_smooth_workspace_bytes(B, H, T, W, C), out)
+    check(lib.kccot_smooth_bwd_f32(ptr(g), ptr(out), ptr(mx), B, H, T, W, C, sigma, radius, axes, ptr(din), ws, wsb,
+                                   stream_of(out)), "smooth_bwd")
+    torch.cuda.synchronize()
+    return din
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 8, 9, 10, 2), (2, 40, 12, 8, 1), (1, 12, 33, 12, 1), (2, 9, 70, 12, 3), (4, 64, 30, 64, 1),
+                                   (2, 6, 8, 20, 1), (3, 16, 7, 12, 3), (64, 64, 30, 64, 1)])
+@pytest.mark.parametrize("ties", ["none", "one", "corners", "cluster", "many"])
+def test_folded_backward_equals_the_two_pass_backward(shape, ties):
+    """Option "smooth_bwd_fold": the first adjoint stage gathers sum(g * out) and the arg-max positions itself and
+    maxnorm_bwd_fixup subtracts corr * A^T [out == 1] sparsely afterwards (= 2: at every size; the default 1 does so
+    for large tensors only, where the two tensor reads saved outweigh the extra launches), against the backward that computes
+    the two sums in a pass of its own first and folds the correction into the first stage's loads (= 0, the round-2 path,
+    pinned to fp64 autograd by test_smoothing_gradient_matches_autograd).  Planted arg-max sets: none; one; the tensor's
+    corners and border positions (REFLECT folds several taps onto one neighbour); a cluster of adjacent elements inside
+    one workgroup's lines (> TIE_PER_WG in one record -> dense fallback on the device) and a few spread ones (overlapping
+    neighbourhoods, sparse path); > 32 spread ones (dense fallback).  A^T is linear: both orders agree to rounding."""
+    import torch
+    from kccotgan_amd import _lib
+    rng = np.random.default_rng(sum(shape) + len(ties))
+    n = int(np.prod(shape))
+    out = rng.random(shape, dtype=np.float32) * 0.98
+    flat = out.reshape(-1)
+    if ties == "one":
+        flat[rng.integers(n)] = 1.0
+    elif ties == "corners":
+        B, H, T, W, C = shape
+        for idx in ((0, 0, 0, 0, 0), (B - 1, H - 1, T - 1, W - 1, C - 1), (0, 1, T - 2, 0, 0), (B - 1, 0, 1, W - 2, C - 1),
+                    (0, H - 1, 0, W - 1, 0), (0, 2, 2, 2, 0), (0, 2, 3, 2, 0)):
+            out[idx] = 1.0
+    elif ties == "cluster":
+        start = int(rng.integers(n - 8))
+        flat[start:start + 6] = 1.0
+    elif ties == "many":
+        flat[rng.choice(n, size=45, replace=False)] = 1.0
+    g = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda()
+    o = torch.from_numpy(out).cuda()
+    mx = torch.tensor([1.7], device="cuda")
+    for radius in (3, 4):
+        if min(shape[1:4]) <= radius:
+            continue
+        for axes in (_lib.SMOOTH_T, _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W):
+            res = {}
+            for fold in (2, 1, 0):
+                for generic in (0, 1):
+                    with _lib.options(smooth_bwd_fold=fold, smooth_generic=generic):
+                        res[fold, generic] = _bwd(g, o, mx, radius, axes)
+            with _lib.options(smooth_stream=0):
+                legacy = _bwd(g, o, mx, radius, axes)
+            scale = float(legacy.abs().max())
+            # the two-pass kernels sum g * out in fp32 partials (the folded stage in fp64): at 7.9 M elements that alone
+            # moves the correction -- the largest entry of the gradient -- by 3e-6 of itself
+            tol = (3e-6 if n < 1 << 20 else 1e-5) * scale
+            for key, val in res.items():
+                assert float((val - legacy).abs().max()) <= tol, (shape, ties, radius, axes, key)
+            # the sparse fix-up is deterministic: a second run gives the same bits
+            with _lib.options(smooth_bwd_fold=2):
+                assert torch.equal(_bwd(g, o, mx, radius, axes), res[2, 0])
