@@ -72,8 +72,6 @@ const char* kccot_last_error(void);
  *   apply_f32                 0        1: the video gradient dfake = W [X;Y] on the f32-input MFMA kernel, likewise
  *   cost_tiled                1        0: no tiled Gram kernels for B % 128 == 0 (the blocked or direct path serves instead)
  *   cost_tile256              1        0: B % 256 == 0 runs the 128-row tiles of cost_tiled.hip instead of the 256-row ones
- *   cost_tile256_w8           0        wave layout of the 256-row tiles: bit 0 = the (X_i, E_i) pairs, bit 1 = the off-diagonal
- *                                      pairs with 8 waves per workgroup (two per SIMD, 4 x 2 tiles each) instead of 4
  *   cost_blocked              1        0: no 64 x 64-block MFMA path for B % 64 == 0 (the direct VALU kernel serves instead)
  *   apply_m256                1        0: the video gradient of B % 256 == 0 in 64-row blocks instead of 256-row tiles
  *   sinkhorn_shortcut         1        0: execute every Sinkhorn iteration; 1: skip iterations EXACTLY once the fp32 state is

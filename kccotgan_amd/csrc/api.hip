@@ -24,7 +24,6 @@ static const OptDesc g_desc[OPT_COUNT] = {
     {"apply_f32", 0, 0, 1},
     {"cost_tiled", 1, 0, 1},
     {"cost_tile256", 1, 0, 1},
-    {"cost_tile256_w8", 0, 0, 3},
     {"cost_blocked", 1, 0, 1},
     {"apply_m256", 1, 0, 1},
     {"sinkhorn_shortcut", 1, 0, 1},

@@ -51,17 +51,11 @@ __host__ __device__ inline int q256_pair_slot(int nt, int pa, int pb) { return p
 // SAME (a diagonal pair, pa == pb: only panel A is staged) and RAGGED (K % 32 != 0: the last granule of the last chunk is
 // partial, values past K are zeroed) are template parameters so that the staging code of each form is straight-line and the
 // compiler interleaves ALL of it with the MFMAs of the step.
-// NW = 4: one wave per SIMD, 4 x 4 tiles each.  NW = 8 (off-diagonal forms only): two waves per SIMD, 4 x 2 tiles each, half
-// the staging each -- the same LDS traffic and VALU work per MFMA, but a wave that sits in a VMEM issue, an s_waitcnt or the
-// stage barrier no longer leaves its SIMD's matrix pipe without an issuer.
-template <bool EPAIR, bool SAME, bool RAGGED, int NW>
+template <bool EPAIR, bool SAME, bool RAGGED>
 __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int chunk_id, unsigned char* zs0, unsigned char* zs1) {
-    static_assert(NW == 4 || (NW == 8 && !SAME), "the triangular tile map of a diagonal pair is written for four waves");
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    constexpr int RS = 8 * NW;                 // rows staged per pass of the workgroup
-    constexpr int NPA = QP / RS;               // passes per panel
-    constexpr int NP = SAME ? NPA : 2 * NPA;
+    constexpr int NP = SAME ? 8 : 16;
     // granules in flight: a diagonal pair stages half as much and has the registers for two (its steps are short: 60
     // MFMAs against 96, so one step of load latency cover is not enough)
     constexpr int DEPTH = SAME ? 2 : 1;
@@ -70,7 +64,7 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
     const int64_t kend = (kbeg + a.chunk < K) ? kbeg + a.chunk : K;
     const int ng = (int)((kend - kbeg + QG - 1) / QG);
 
-    // ---- staging role: thread = (row rr + RS p, columns 4 q .. 4 q + 3 of the granule), p < NPA panel A, p >= NPA panel B
+    // ---- staging role: thread = (row rr + 32 p, columns 4 q .. 4 q + 3 of the granule), p < 8 panel A, p >= 8 panel B
     const int q = t & 7, rr = t >> 3;
     // Loads (and the E stores) go through buffer descriptors: panel base in SGPRs, the lane's row / column part in ONE
     // 32-bit voffset, the pass's 32-row step as a scalar offset -- sixteen 64-bit flat addresses cost 32 registers.
@@ -86,7 +80,7 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
     const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(apanel), 0, 0xFFFFFFFFu, 0x00020000);
     const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bpanel), 0, 0xFFFFFFFFu, 0x00020000);
     const auto re = __builtin_amdgcn_make_buffer_rsrc(a.e + (int64_t)pa * QP * K, 0, 0xFFFFFFFFu, 0x00020000);   // EPAIR only
-    const unsigned rstep = (unsigned)(RS * K * 4);                           // bytes; the last pass + a row < 4 GiB: K <= 2^22 (host)
+    const unsigned rstep = (unsigned)(32 * K * 4);                           // bytes; 7 * rstep + a row < 4 GiB: K <= 2^22 (host)
     const unsigned lrow = (unsigned)((int64_t)rr * K * 4);
     const int64_t kmax = K - 4;                                              // K % 4 == 0, K >= 256 (host checks)
     const int woff = rr * QROWB + 4 * q;                                     // + 32 p rows
@@ -100,12 +94,12 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
         k = k < kmax ? k : kmax;
         const unsigned vo = lrow + (unsigned)(k * 4);
 #pragma unroll
-        for (int p = 0; p < NPA; ++p)
+        for (int p = 0; p < 8; ++p)
             G[p] = __builtin_bit_cast(float4, (qu32x4)__builtin_amdgcn_raw_buffer_load_b128(ra, (int)vo, (int)(p * rstep), 0));
         if constexpr (!SAME) {
 #pragma unroll
-            for (int p = 0; p < NPA; ++p)
-                G[NPA + p] = __builtin_bit_cast(float4, (qu32x4)__builtin_amdgcn_raw_buffer_load_b128(rb, (int)vo, (int)(p * rstep), 0));
+            for (int p = 0; p < 8; ++p)
+                G[8 + p] = __builtin_bit_cast(float4, (qu32x4)__builtin_amdgcn_raw_buffer_load_b128(rb, (int)vo, (int)(p * rstep), 0));
         }
     };
     // granule g has landed: E rows formed (EPAIR), the even step's pairs split into `zs`, the odd step's kept in `carry`
@@ -116,21 +110,21 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             float4 v = G[p];
-            if (EPAIR && p >= NPA) {
-                v.x -= G[p - NPA].x; v.y -= G[p - NPA].y; v.z -= G[p - NPA].z; v.w -= G[p - NPA].w;
+            if (EPAIR && p >= 8) {
+                v.x -= G[p - 8].x; v.y -= G[p - 8].y; v.z -= G[p - 8].z; v.w -= G[p - 8].w;
                 // unconditional: a granule past the end of the chunk re-writes the E values of columns another workgroup
                 // owns -- the same bits from the same inputs -- rather than put a branch into the step's block
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(qu32x4, v), re, (int)vo, (int)((p - NPA) * rstep), 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(qu32x4, v), re, (int)vo, (int)((p - 8) * rstep), 0);
             }
             if (RAGGED) { v.x = kok ? v.x : 0.f; v.y = kok ? v.y : 0.f; v.z = kok ? v.z : 0.f; v.w = kok ? v.w : 0.f; }
-            gq_split_store<QPLANE>(zs, woff + RS * p * QROWB, v.x, v.y);
+            gq_split_store<QPLANE>(zs, woff + 32 * p * QROWB, v.x, v.y);
             carry[p] = make_float2(v.z, v.w);
         }
     };
     auto emit_odd = [&](unsigned char* zs) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            gq_split_store<QPLANE>(zs, woff + RS * p * QROWB, carry[p].x, carry[p].y);
+            gq_split_store<QPLANE>(zs, woff + 32 * p * QROWB, carry[p].x, carry[p].y);
         }
     };
 
@@ -142,13 +136,11 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
     //     wave 1: rows {4,5} x cols {4..7} (its (5,4) is redundant) + (6,6), (6,7)      wave 3: rows {2,3} x cols {4..7} + (7,7)
     // (waves 2 and 3 run their extra tile twice instead of branching; the copy is not stored).  The tiles below the
     // diagonal are never written: gram_q256_reduce zeroes them, q256_gram reads (min, max).
-    // Eight waves: wave (wr, wc) owns rows 128 wr .. x columns 64 wc .. = 4 x 2 tiles.
-    constexpr int NT = SAME ? 10 : (NW == 8 ? 8 : 16);
-    constexpr int NTC = NW == 8 ? 2 : 4;                                     // column tiles of a wave's block
-    const int wr = NW == 8 ? wave >> 2 : wave >> 1, wc = NW == 8 ? wave & 3 : wave & 1;
+    constexpr int NT = SAME ? 10 : 16;
+    const int wr = wave >> 1, wc = wave & 1;
     const int lo = (lane & 31) * QROWB + 16 * (lane >> 5);                   // row (lane & 31), k half (lane >> 5) of the step
     const int tr0 = SAME ? (wave == 1 ? 4 : (wave == 3 ? 2 : 0)) : 4 * wr;   // first row tile of the block
-    const int tc0 = SAME ? (wave == 0 ? 0 : 4) : NTC * wc;                   // first column tile of the block
+    const int tc0 = SAME ? (wave == 0 ? 0 : 4) : 4 * wc;                     // first column tile of the block
     const int ter = SAME ? (wave == 0 ? 2 : (wave == 1 ? 6 : (wave == 2 ? 3 : 7))) : 0;   // SAME: the extra tiles (ter, ter), (ter, ter + 1)
     const int aoff = tr0 * 32 * QROWB + lo;
     const int boff = (SAME ? 0 : QP * QROWB) + tc0 * 32 * QROWB + lo;        // a diagonal pair reads its B fragments from the A rows
@@ -176,13 +168,13 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
         } else {
             // two B tiles at a time (24 fragment registers instead of 48; the A fragments are read twice per step)
 #pragma unroll
-            for (int jh = 0; jh < NTC / 2; ++jh) {
+            for (int jh = 0; jh < 2; ++jh) {
                 const QFrag b0 = gq_frag<QPLANE>(zs, boff + (2 * jh) * 32 * QROWB), b1 = gq_frag<QPLANE>(zs, boff + (2 * jh + 1) * 32 * QROWB);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const QFrag af = gq_frag<QPLANE>(zs, aoff + i * 32 * QROWB);
-                    gq_mfma6(acc[NTC * i + 2 * jh], af, b0);
-                    gq_mfma6(acc[NTC * i + 2 * jh + 1], af, b1);
+                    gq_mfma6(acc[4 * i + 2 * jh], af, b0);
+                    gq_mfma6(acc[4 * i + 2 * jh + 1], af, b1);
                 }
             }
         }
@@ -245,7 +237,7 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
     for (int t2 = 0; t2 < NT; ++t2) {
         int trow, tcol;
         if (SAME && t2 >= 8) { trow = ter; tcol = ter + (t2 - 8); }
-        else { trow = tr0 + t2 / NTC; tcol = tc0 + t2 % NTC; }
+        else { trow = tr0 + t2 / 4; tcol = tc0 + t2 % 4; }
         if (SAME && t2 == 9 && wave >= 2) continue;                          // the duplicate of waves 2 and 3
         float* ot = o + (32 * trow) * QP + 32 * tcol;
 #pragma unroll
@@ -261,8 +253,8 @@ __host__ __device__ inline int q256_mode_pairs(int mode, int nx) {
     return mode == Q256_EPAIR ? nx : (mode == Q256_DIAG ? nt : nt * (nt - 1) / 2 - nx);
 }
 
-template <int MODE, bool RAGGED, int NW>
-__global__ __launch_bounds__(64 * NW) void gram_q256(Q256Args a) {
+template <int MODE, bool RAGGED>
+__global__ __launch_bounds__(256) void gram_q256(Q256Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char zs0[QSLOT];
     __shared__ __attribute__((aligned(16))) unsigned char zs1[QSLOT];
     // XCD-aware block -> (pair, chunk) map: workgroups are dealt to the 8 XCDs round-robin, so XCD x = id % 8 takes the
@@ -289,7 +281,7 @@ __global__ __launch_bounds__(64 * NW) void gram_q256(Q256Args a) {
     }
     if ((int64_t)chunk_id * a.chunk >= a.K) return;                          // an empty trailing chunk
     // (the integer division above runs on the VALU: make the uniformity of what the buffer descriptors are built from explicit)
-    q256_body<MODE == Q256_EPAIR, MODE == Q256_DIAG, RAGGED, NW>(a, __builtin_amdgcn_readfirstlane(pa), __builtin_amdgcn_readfirstlane(pb),
+    q256_body<MODE == Q256_EPAIR, MODE == Q256_DIAG, RAGGED>(a, __builtin_amdgcn_readfirstlane(pa), __builtin_amdgcn_readfirstlane(pb),
                                                              __builtin_amdgcn_readfirstlane(chunk_id), zs0, zs1);
 }
 
@@ -433,17 +425,17 @@ int run_gram_q256(const CostBatch& cb, int64_t K, float sc, int T, int J, void* 
         for (int mode = 0; mode < 3; ++mode) {
             const int np = q256_mode_pairs(mode, pl.nx);
             if (np == 0) continue;
-            const dim3 grid(np * pl.nchunk);
-            const int w8 = opt(OPT_COST_TILE256_W8);                         // bit 0: the (X_i, E_i) pairs, bit 1: the off-diagonal pairs
-#define KCCOT_Q256(MODE, NW)                                                                                   \
-    do {                                                                                                       \
-        if (ragged) hipLaunchKernelGGL((gram_q256<MODE, true, NW>), grid, dim3(64 * NW), 0, st, qa);           \
-        else hipLaunchKernelGGL((gram_q256<MODE, false, NW>), grid, dim3(64 * NW), 0, st, qa);                 \
-    } while (0)
-            if (mode == Q256_EPAIR) { if (w8 & 1) KCCOT_Q256(Q256_EPAIR, 8); else KCCOT_Q256(Q256_EPAIR, 4); }
-            else if (mode == Q256_DIAG) KCCOT_Q256(Q256_DIAG, 4);
-            else { if (w8 & 2) KCCOT_Q256(Q256_OFF, 8); else KCCOT_Q256(Q256_OFF, 4); }
-#undef KCCOT_Q256
+            const dim3 grid(np * pl.nchunk), block(256);
+            if (mode == Q256_EPAIR) {
+                if (ragged) hipLaunchKernelGGL((gram_q256<Q256_EPAIR, true>), grid, block, 0, st, qa);
+                else hipLaunchKernelGGL((gram_q256<Q256_EPAIR, false>), grid, block, 0, st, qa);
+            } else if (mode == Q256_DIAG) {
+                if (ragged) hipLaunchKernelGGL((gram_q256<Q256_DIAG, true>), grid, block, 0, st, qa);
+                else hipLaunchKernelGGL((gram_q256<Q256_DIAG, false>), grid, block, 0, st, qa);
+            } else {
+                if (ragged) hipLaunchKernelGGL((gram_q256<Q256_OFF, true>), grid, block, 0, st, qa);
+                else hipLaunchKernelGGL((gram_q256<Q256_OFF, false>), grid, block, 0, st, qa);
+            }
             if ((rc = launch_status("gram_q256"))) return rc;
         }
         const int nvalid = (int)((K + pl.chunk - 1) / pl.chunk);

@@ -9,7 +9,6 @@ enum Option {
     OPT_APPLY_F32,               // "apply_f32"
     OPT_COST_TILED,              // "cost_tiled"
     OPT_COST_TILE256,            // "cost_tile256"
-    OPT_COST_TILE256_W8,         // "cost_tile256_w8"
     OPT_COST_BLOCKED,            // "cost_blocked"
     OPT_APPLY_M256,              // "apply_m256"
     OPT_SK_SHORTCUT,             // "sinkhorn_shortcut"
