@@ -6,7 +6,7 @@ exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so it 
 kernels whose reads are global_load_dwordx4 streams; WRITE_SIZE is exact for 16-B-per-lane stores."""
 import csv, json, os, sys, collections
 out = sys.argv[1]
-WIDE_READERS = ("gram128_partial", "gram128_partial_x3", "gram128_partial_x3ws", "apply_coeffs_mfma", "apply_coeffs_x3", "cost_direct_partial", "gram_tile_x3")
+WIDE_READERS = ("gram128_partial", "gram128_partial_x3", "gram128_partial_x3ws", "apply_coeffs_mfma", "apply_coeffs_x3", "cost_direct_partial", "gram_tile_x3", "gram_q256", "rows_gram", "apply_coeffs_x3_m256", "apply_coeffs_x3_m256n128")
 res = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     p = os.path.join(out, c + "_counters.csv")
