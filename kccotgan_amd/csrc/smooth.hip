@@ -967,22 +967,20 @@ static int launch_tw_plane(const float* in, float* out, int64_t n, int T, int W,
                            hipStream_t st) {
     const size_t lds = tw_plane_lds(T, W, C, radius, adjoint);
     const dim3 grid((unsigned)(n / ((int64_t)T * W * C)));
-#define KCCOT_TWP(RR, AA, CCC)                                                                                         \
+    // (the dynamic-LDS limit is raised on every launch that needs it: a per-process flag would be wrong for a second device)
+#define KCCOT_TWP(RR, CCC)                                                                                             \
     do {                                                                                                               \
-        static bool big_done = false;                                                                                  \
-        if (lds > 64 * 1024 && !big_done) {                                                                            \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_tw_plane<RR, AA, CCC>),                      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)             \
-                return fail(KCCOT_EUNSUPPORTED, "smooth_tw_plane: cannot raise the dynamic LDS limit");                \
-            big_done = true;                                                                                           \
-        }                                                                                                              \
-        hipLaunchKernelGGL((smooth_tw_plane<RR, AA, CCC>), grid, dim3(256), lds, st, in, out, T, W, tp);               \
+        if (lds > 64 * 1024 &&                                                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_tw_plane<RR, false, CCC>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                 \
+            return fail(KCCOT_EUNSUPPORTED, "smooth_tw_plane: cannot raise the dynamic LDS limit");                    \
+        hipLaunchKernelGGL((smooth_tw_plane<RR, false, CCC>), grid, dim3(256), lds, st, in, out, T, W, tp);            \
     } while (0)
-#define KCCOT_TWP_C(RR, AA)                                                                     \
-    switch (C) { case 1: KCCOT_TWP(RR, AA, 1); break; case 2: KCCOT_TWP(RR, AA, 2); break;      \
-                 case 3: KCCOT_TWP(RR, AA, 3); break; default: KCCOT_TWP(RR, AA, 4); break; }
-    if (radius == 3) { if (adjoint) { KCCOT_TWP_C(3, true) } else { KCCOT_TWP_C(3, false) } }
-    else { if (adjoint) { KCCOT_TWP_C(4, true) } else { KCCOT_TWP_C(4, false) } }
+#define KCCOT_TWP_C(RR)                                                                 \
+    switch (C) { case 1: KCCOT_TWP(RR, 1); break; case 2: KCCOT_TWP(RR, 2); break;      \
+                 case 3: KCCOT_TWP(RR, 3); break; default: KCCOT_TWP(RR, 4); break; }
+    if (adjoint) return fail(KCCOT_EUNSUPPORTED, "smooth_tw_plane: the adjoint runs as separate W and T stages");
+    if (radius == 3) { KCCOT_TWP_C(3) } else { KCCOT_TWP_C(4) }
 #undef KCCOT_TWP_C
 #undef KCCOT_TWP
     return launch_status("smooth_tw_plane");
