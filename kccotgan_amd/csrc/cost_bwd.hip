@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3(const unsigned short* __r
 // planes) now feeds 4 x as many MFMAs, the accumulators stay in registers (2 x 2 tiles per consumer wave), the
 // output is written once.  W does not fit registers any more (256 x R x 3 planes): the consumers stream their
 // fragments from L2 (the bf16 planes of W are <= 3 MB), three k-steps ahead of use.
-constexpr int AB_MT = 256;
+constexpr int AB_MT = 256;                        // the tallest output tile
 
 // W3 [3][Bt][Rt] (stack rows contiguous per output row) -> fragment-major tiles for apply_coeffs_x3_m256:
 //   Wt3[((pl * Bt/32 + m/32) * Rt/16 + r/16) * 512 + ((m % 32) + 32 * ((r % 16) / 8)) * 8 + r % 8]
@@ -637,6 +637,172 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_m256(const unsigned short
             const int64_t m = m0 + 64 * w + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (col < K) { out[m * K + col] = acc00[r]; out[(m + 32) * K + col] = acc10[r]; }
             if (col + 32 < K) { out[m * K + col + 32] = acc01[r]; out[(m + 32) * K + col + 32] = acc11[r]; }
+        }
+    }
+}
+
+// ---- the same one-launch form for output blocks that are not multiples of 256 rows (round 3) -----------------------------
+// The output tile of a workgroup is (32 RT WR) rows x 64 columns: consumer wave (wr, wc) of a WR x WC grid owns RT x CT
+// MFMA tiles, CT WC = 2.  <1, 2, 4, 1> = 128 rows (configs[2]: B = 128 ran 2 x 2 launches of the 64-row block form, every
+// stack chunk staged twice and the output read-modified-written: 0.69 of the 1.02 ms of its loss step), <1, 1, 2, 2> = 64
+// rows and <1, 1, 1, 2> = 32 rows (two consumer waves; a rank's rows of the batch-sharded loss: one launch instead of
+// 2B/128 accumulating ones).  Producers and stage pipeline are those of apply_coeffs_x3_m256, which stays as measured.
+template <int RT, int CT, int WR, int WC>
+__global__ __launch_bounds__(512) void apply_coeffs_x3_rows(const unsigned short* __restrict__ W3, int Bt, int Rt,
+                                                            const float* __restrict__ src1, int n1,
+                                                            const float* __restrict__ src2, int n2, int64_t K,
+                                                            int64_t ntiles, float* __restrict__ out) {
+    static_assert(CT * WC == 2 && WR * WC <= 4, "a workgroup tile is 64 columns wide and has four consumer waves");
+    constexpr int MT = 32 * RT * WR;
+    __shared__ __attribute__((aligned(16))) unsigned char zs[2 * AX_BUF];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nchunk = (n1 + n2) / AM_ROWS;                   // 128-row chunks; n1 % 128 == 0 (host)
+    const int m0 = blockIdx.y * MT;
+    if (wave < 4) {
+        // ---------------------------------------------------------------- producers (as apply_coeffs_x3)
+        const int c4 = (t & 15) * 4, rp0 = t >> 4;
+        // TWO chunks of loads in flight per producer thread (v: even stages, w: odd stages, each set re-issued right after
+        // it has been split): a chunk is 192 MFMAs per consumer wave = 2.6 us at the matrix pipe's full rate, less than the
+        // HBM round trip under load -- with one chunk in flight the consumers waited for the producers at every barrier
+        // (the diagnostic build with NOTHING but MFMAs, barriers and these loads ran at 49 % of the 2.48 PFLOP/s that
+        // tools/micro/mfma_peak.hip sustains).
+        float4 v[8], w[8];
+        auto load_stage = [&](float4 (&dst)[8], int64_t tile, int c) {
+            const int g0 = c * AM_ROWS;
+            const float* base = g0 < n1 ? src1 + (int64_t)g0 * K : src2 + (int64_t)(g0 - n1) * K;
+            const int64_t col = tile * AM_COLS + c4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 2 * (rp0 + 16 * (j >> 1)) + (j & 1);
+                dst[j] = (col + 4 <= K) ? *reinterpret_cast<const float4*>(base + (int64_t)r * K + col)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto split_stage = [&](const float4 (&src)[8], unsigned char* zb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * (rp0 + 16 * i);
+                const float a[4] = {src[2 * i].x, src[2 * i].y, src[2 * i].z, src[2 * i].w};
+                const float b[4] = {src[2 * i + 1].x, src[2 * i + 1].y, src[2 * i + 1].z, src[2 * i + 1].w};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    unsigned ha, ma, la, hb, mb, lb;
+                    split3u(a[cc], ha, ma, la);
+                    split3u(b[cc], hb, mb, lb);
+                    const int off = (c4 + cc) * AX_COLP + r * 2;
+                    *reinterpret_cast<unsigned*>(zb + off) = __builtin_amdgcn_perm(hb, ha, 0x07060302u);
+                    *reinterpret_cast<unsigned*>(zb + AX_PLANE + off) = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
+                    *reinterpret_cast<unsigned*>(zb + 2 * AX_PLANE + off) = __builtin_amdgcn_perm(lb, la, 0x07060302u);
+                }
+            }
+        };
+        // stage sequence: (tile, chunk) pairs in order; `nt`/`nc` walk two stages ahead of the one being split
+        int64_t tile = blockIdx.x, nt = tile;
+        int c = 0, nc = 0, buf = 0;
+        auto advance = [&](int64_t& tt, int& cc) { if (++cc == nchunk) { cc = 0; tt += gridDim.x; } };
+        if (nt < ntiles) load_stage(v, nt, nc);
+        advance(nt, nc);
+        if (nt < ntiles) load_stage(w, nt, nc);
+        advance(nt, nc);
+        while (tile < ntiles) {
+            split_stage(v, zs + buf * AX_BUF);
+            if (nt < ntiles) load_stage(v, nt, nc);
+            advance(nt, nc);
+            advance(tile, c);
+            buf ^= 1;
+            __syncthreads();
+            if (tile >= ntiles) break;
+            split_stage(w, zs + buf * AX_BUF);
+            if (nt < ntiles) load_stage(w, nt, nc);
+            advance(nt, nc);
+            advance(tile, c);
+            buf ^= 1;
+            __syncthreads();
+        }
+        __syncthreads();          // the consumers' closing barrier
+        return;
+    }
+    // -------------------------------------------------------------------- consumers
+    const int w = wave - 4;
+    const bool active = WR * WC == 4 || w < WR * WC;           // (32- and 64-row tiles leave consumer waves without a tile:
+    const int wr = active ? w / WC : 0, wc = active ? w % WC : 0;   //  they only keep the barriers)
+    const int mw = m0 + 32 * RT * wr;                         // first output row of this wave
+    const int nsteps = Rt >> 4;                               // k-steps per tile (a multiple of 8)
+    // W3 is the fragment-major copy (retile_coeffs): row tile mt, k-step g -> 1 KiB at ((pl*Bt/32 + mt)*nsteps + g)*512
+    const int64_t plane = (int64_t)Bt * Rt;
+    const unsigned short* wb0 = W3 + (int64_t)(mw / 32) * nsteps * 512 + lane * 8;
+    abf16x8 A[4][RT][3];                                      // ring of fragment sets: step g lives in A[g & 3]
+    auto ldA = [&](int g, int slot) {
+        const int64_t o = (int64_t)512 * g;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+                A[slot][i][pl] = *reinterpret_cast<const abf16x8*>(wb0 + (int64_t)i * nsteps * 512 + pl * plane + o);
+    };
+    if (active) { ldA(0, 0); ldA(1, 1); ldA(2, 2); }
+    const int boff0 = ((lane & 31) + 32 * CT * wc) * AX_COLP + 16 * (lane >> 5);
+    int buf = 0;
+    __syncthreads();                                          // the first stage is in buffer 0
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[RT][CT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int c = 0; c < nchunk; ++c, buf ^= 1) {
+            if (active) {
+                const unsigned char* zb = zs + buf * AX_BUF;
+                abf16x8 Bf[2][CT][3];                         // [step parity][column tile][piece]: one k-step ahead
+                auto ldB = [&](int st, int par) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int j = 0; j < CT; ++j) {
+                            uint2* p0 = reinterpret_cast<uint2*>(&Bf[par][j][pl]);
+                            p0[0] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff0 + j * 32 * AX_COLP + 32 * st);
+                            p0[1] = *reinterpret_cast<const uint2*>(zb + pl * AX_PLANE + boff0 + j * 32 * AX_COLP + 32 * st + 8);
+                        }
+                };
+                ldB(0, 0);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    // W fragments three k-steps ahead (past the end of this tile's walk: the first steps of the next tile),
+                    // the staged tile's fragments one k-step ahead; the scheduling barrier keeps hipcc from sinking the loads
+                    // back down to their first use (it did: L2 latency landed on every MFMA group)
+                    int gn = c * 8 + s + 3;
+                    if (gn >= nsteps) gn -= nsteps;
+                    ldA(gn, (s + 3) & 3);
+                    if (s < 7) ldB(s + 1, (s + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // product-major order over the accumulators (no MFMA waits on the one before it), smallest terms first
+#define KCCOT_A4(PA, PB)                                                                                              \
+                    _Pragma("unroll") for (int i = 0; i < RT; ++i)                                                    \
+                        _Pragma("unroll") for (int j = 0; j < CT; ++j)                                                \
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 3][i][PA], Bf[s & 1][j][PB], acc[i][j], 0, 0, 0);
+                    KCCOT_A4(1, 1) KCCOT_A4(0, 2) KCCOT_A4(2, 0) KCCOT_A4(0, 1) KCCOT_A4(1, 0) KCCOT_A4(0, 0)
+#undef KCCOT_A4
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();                                  // this stage is consumed; the next one is staged
+        }
+        if (active) {
+            const int64_t col = tile * AM_COLS + 32 * CT * wc + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    if (col + 32 * j < K) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int64_t m = mw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            out[m * K + col + 32 * j] = acc[i][j][r];
+                        }
+                    }
         }
     }
 }
@@ -805,8 +971,8 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
         const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);   // 2 workgroups per CU (VGPR-limited)
         const int R = n1 + n2;
         // large batches: 256-row output tiles over the whole stack, one launch (option "apply_m256" = 0: the block form)
-        if (x3 && Wt3 && Bout % AB_MT == 0 && Bt % 32 == 0 && n1 % AM_ROWS == 0 && n2 % AM_ROWS == 0 && R == Rt &&
-            opt(OPT_APPLY_M256)) {
+        if (x3 && Wt3 && Bout % 32 == 0 && (Bout % 64 == 0 || Bout == 32) && Bt % 32 == 0 && n1 % AM_ROWS == 0 &&
+            n2 % AM_ROWS == 0 && R == Rt && (R > AM_ROWS || Bout > 64) && opt(OPT_APPLY_M256)) {
             const unsigned gxb = (unsigned)(ntiles < 256 ? ntiles : 256);
             // W3 is positioned at the first wanted output row (a multiple of 256 here): retile from the plane base
             const int64_t row0 = (W3 - W3base) / Rt;
@@ -819,13 +985,22 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
             // tail of the persistent tile loop costs more than the W stream saves (B = 256, K = 368 640: 0.73 vs 0.68 ms;
             // B = 512, K = 2.36 M: 13.2 vs 13.8 ms).
             const int64_t nt128 = (K + AY_COLS - 1) / AY_COLS;
-            if (nt128 >= 20 * 256 && n1 % AY_ROWS == 0 && n2 % AY_ROWS == 0) {
+            if (Bout % AB_MT == 0 && nt128 >= 20 * 256 && n1 % AY_ROWS == 0 && n2 % AY_ROWS == 0) {
                 const unsigned gy = (unsigned)(nt128 < 256 ? nt128 : 256);
                 hipLaunchKernelGGL(apply_coeffs_x3_m256n128, dim3(gy, Bout / AB_MT), dim3(512), 0, st, Wuse, Bt, Rt, s1, n1, s2, n2,
                                    K, nt128, out);
                 return launch_status("apply_coeffs_x3_m256n128");
             }
-            hipLaunchKernelGGL(apply_coeffs_x3_m256, dim3(gxb, Bout / AB_MT), dim3(512), 0, st, Wuse, Bt, Rt, s1, n1, s2, n2, K, ntiles, out);
+            // the tallest tile that divides the wanted rows
+#define KCCOT_APPLY_ROWS(RT, CT, WR, WC)                                                                                         \
+            hipLaunchKernelGGL((apply_coeffs_x3_rows<RT, CT, WR, WC>), dim3(gxb, Bout / (32 * RT * WR)), dim3(512), 0, st, Wuse, Bt, Rt, \
+                               s1, n1, s2, n2, K, ntiles, out)
+            if (Bout % AB_MT == 0)
+                hipLaunchKernelGGL(apply_coeffs_x3_m256, dim3(gxb, Bout / AB_MT), dim3(512), 0, st, Wuse, Bt, Rt, s1, n1, s2, n2, K, ntiles, out);
+            else if (Bout % 128 == 0) KCCOT_APPLY_ROWS(1, 2, 4, 1);
+            else if (Bout % 64 == 0) KCCOT_APPLY_ROWS(1, 1, 2, 2);
+            else KCCOT_APPLY_ROWS(1, 1, 1, 2);
+#undef KCCOT_APPLY_ROWS
             return launch_status("apply_coeffs_x3_m256");
         }
         for (int ob = 0; ob < Bout; ob += 64) {
@@ -924,7 +1099,7 @@ static int cost3_bwd_rows_impl(const float* g3, const float* gscale, const float
     }
     unsigned short* Wt3 = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(W3) + align_up((size_t)3 * B * 2 * B * sizeof(unsigned short), 256));
     return launch_apply(Wt + row_begin, B, real, B, fake, B, row_count, K, dfake, st, W3 + (int64_t)row_begin * 2 * B, B, 2 * B,
-                        W3, (B % AB_MT == 0 && row_begin % AB_MT == 0) ? Wt3 : nullptr);
+                        W3, (B % 32 == 0 && row_begin % 32 == 0) ? Wt3 : nullptr);
 }
 
 extern "C" int kccot_pairwise_cost3_bwd_rows_f32(const float* g3, const float* real, const float* fake, int B,

@@ -1176,13 +1176,14 @@ def test_full_size_configs_3_and_4_against_the_oracle(G, shape, Lc):
         assert abs(float(rbf_mmd2(real, real.clone()))) <= 1e-6
 
 
-def test_large_batch_video_gradient_forms_agree(G, L):
-    """B = 256: the one-launch 256-row-tile video gradient (apply_coeffs_x3_m256; its 128-column form takes over at
-    K >= 655 360 and is checked against the fp64 formula at configs[4] in tests/test_gpu_fullsize_grads.py) against the
-    64-row block form (option "apply_m256" = 0): same exact split, same products, another tiling of the stack -- equal to
-    fp32 summation order (1e-6 of max|grad|)."""
-    B, H, T, W, C = 256, 8, 10, 8, 5          # K = 3200: 50 column tiles of 64
-    gen = torch.Generator(device=DEV).manual_seed(4242)
+@pytest.mark.parametrize("B", [256, 128, 192, 384])
+def test_large_batch_video_gradient_forms_agree(G, L, B):
+    """The one-launch video gradient (B = 256: apply_coeffs_x3_m256, 256-row tiles; its 128-column form takes over at
+    K >= 655 360 and is checked against the fp64 formula at configs[4] in tests/test_gpu_fullsize_grads.py; B = 128 / 384:
+    apply_coeffs_x3_rows with 128-row tiles, B = 192: 64-row tiles) against the 64-row block form (option "apply_m256" = 0):
+    same exact split, same products, another tiling of the stack -- equal to fp32 summation order (1e-6 of max|grad|)."""
+    H, T, W, C = 8, 10, 8, 5                  # K = 3200: 50 column tiles of 64
+    gen = torch.Generator(device=DEV).manual_seed(4242 + B)
     real = torch.rand((B, H, T, W, C), device=DEV, generator=gen)
     fake = (real + 0.05 * torch.randn(real.shape, device=DEV, generator=gen)).clamp_(0, 1)
     f = {k: torch.rand((B, T, 8), device=DEV, generator=gen) for k in ("h_fake", "m_real", "h_real", "m_fake")}
@@ -1194,6 +1195,31 @@ def test_large_batch_video_gradient_forms_agree(G, L):
             (grads[mode],) = torch.autograd.grad(loss, fk)
     scale = float(grads["block"].abs().max())
     assert float((grads["tile"] - grads["block"]).abs().max()) <= 1e-6 * scale
+
+
+@pytest.mark.parametrize("B,rows", [(128, 32), (128, 64), (256, 32), (256, 64), (384, 128), (256, 96)])
+def test_video_gradient_of_a_row_block_in_one_launch(G, L, B, rows):
+    """kccot_pairwise_cost3_bwd_rows_f32 (the batch-sharded caller's gradient of ITS samples from the replicated dC):
+    row blocks of 32 / 64 / 128 rows run apply_coeffs_x3_rows in ONE launch over the whole stack (96 rows: no tile height
+    divides them, the block form serves) -- every block of every rank against the same rows of the full-batch gradient
+    and against the block form."""
+    from kccotgan_amd.dist import HipOps as H
+    K = 2560 + 36
+    gen = torch.Generator(device=DEV).manual_seed(777 + B + rows)
+    real = torch.rand((B, K), device=DEV, generator=gen)
+    fake = (real + 0.05 * torch.randn(real.shape, device=DEV, generator=gen)).clamp_(0, 1)
+    f = [torch.rand((B, 6, 8), device=DEV, generator=gen) for _ in range(4)]      # h_fake, h_real, m_real, m_fake
+    g3 = torch.randn((3, B, B), device=DEV, generator=gen)
+    full = H.cost3_bwd_rows(g3, real, fake, f[0], f[1], f[2], f[3], cases.SC, 0, B)
+    scale = float(full[0].abs().max())
+    for r0 in range(0, B - rows + 1, rows):
+        got = H.cost3_bwd_rows(g3, real, fake, f[0], f[1], f[2], f[3], cases.SC, r0, rows)
+        with L.options(apply_m256=0):
+            blk = H.cost3_bwd_rows(g3, real, fake, f[0], f[1], f[2], f[3], cases.SC, r0, rows)
+        assert float((got[0] - full[0][r0:r0 + rows]).abs().max()) <= 1e-6 * scale, (r0, "vs full batch")
+        assert float((got[0] - blk[0]).abs().max()) <= 1e-6 * scale, (r0, "vs block form")
+        for a, b in zip(got[1:], blk[1:]):
+            assert torch.equal(a, b)
 
 
 def test_video_gradient_bf16_split_matches_f32_mfma(G, L):
