@@ -51,7 +51,9 @@ __host__ __device__ inline int q256_pair_slot(int nt, int pa, int pb) { return p
 // SAME (a diagonal pair, pa == pb: only panel A is staged) and RAGGED (K % 32 != 0: the last granule of the last chunk is
 // partial, values past K are zeroed) are template parameters so that the staging code of each form is straight-line and the
 // compiler interleaves ALL of it with the MFMAs of the step.
-template <bool EPAIR, bool SAME, bool RAGGED>
+// HALF (B == 128, round 3): the whole stack [X ; E] is ONE 256-row panel -- a diagonal pair whose rows 128.. are formed in
+// registers from the rows of `fake` the same thread loads (the staging of EPAIR without its E store: nothing else reads E).
+template <bool EPAIR, bool SAME, bool RAGGED, bool HALF = false>
 __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int chunk_id, unsigned char* zs0, unsigned char* zs1) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -70,7 +72,11 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
     // 32-bit voffset, the pass's 32-row step as a scalar offset -- sixteen 64-bit flat addresses cost 32 registers.
     const float* apanel;
     const float* bpanel;
-    if (EPAIR) {
+    static_assert(!HALF || (SAME && !EPAIR), "the single-panel form is a diagonal pair");
+    if (HALF) {
+        apanel = a.x;
+        bpanel = a.f;
+    } else if (EPAIR) {
         apanel = a.x + (int64_t)pa * QP * K;
         bpanel = a.f + (int64_t)pa * QP * K;
     } else {
@@ -94,8 +100,13 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
         k = k < kmax ? k : kmax;
         const unsigned vo = lrow + (unsigned)(k * 4);
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
+        for (int p = 0; p < (HALF ? 4 : 8); ++p)
             G[p] = __builtin_bit_cast(float4, (qu32x4)__builtin_amdgcn_raw_buffer_load_b128(ra, (int)vo, (int)(p * rstep), 0));
+        if constexpr (HALF) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                G[4 + p] = __builtin_bit_cast(float4, (qu32x4)__builtin_amdgcn_raw_buffer_load_b128(rb, (int)vo, (int)(p * rstep), 0));
+        }
         if constexpr (!SAME) {
 #pragma unroll
             for (int p = 0; p < 8; ++p)
@@ -110,6 +121,7 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             float4 v = G[p];
+            if (HALF && p >= 4) { v.x -= G[p - 4].x; v.y -= G[p - 4].y; v.z -= G[p - 4].z; v.w -= G[p - 4].w; }
             if (EPAIR && p >= 8) {
                 v.x -= G[p - 8].x; v.y -= G[p - 8].y; v.z -= G[p - 8].z; v.w -= G[p - 8].w;
                 // unconditional: a granule past the end of the chunk re-writes the E values of columns another workgroup
@@ -247,8 +259,10 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
 
 // MODE 0: the pairs (X_i, E_i), which also write E (launched first); 1: the diagonal pairs (p, p); 2: every other pair.
 // One kernel per mode: each is one straight-line instantiation of the body (two in one kernel spilled registers).
-enum { Q256_EPAIR = 0, Q256_DIAG = 1, Q256_OFF = 2 };
+enum { Q256_EPAIR = 0, Q256_DIAG = 1, Q256_OFF = 2, Q256_HALF = 3 };
 __host__ __device__ inline int q256_mode_pairs(int mode, int nx) {
+    if (nx == 0) return mode == Q256_HALF ? 1 : 0;                           // B == 128: the stack is one panel
+    if (mode == Q256_HALF) return 0;
     const int nt = 2 * nx;
     return mode == Q256_EPAIR ? nx : (mode == Q256_DIAG ? nt : nt * (nt - 1) / 2 - nx);
 }
@@ -266,6 +280,8 @@ __global__ __launch_bounds__(256) void gram_q256(Q256Args a) {
     int pa, pb;
     if (MODE == Q256_EPAIR) {
         pa = slot % np; pb = a.nx + pa;
+    } else if (MODE == Q256_HALF) {
+        pa = pb = 0;
     } else if (MODE == Q256_DIAG) {
         pa = pb = slot % np;
     } else {
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(256) void gram_q256(Q256Args a) {
     }
     if ((int64_t)chunk_id * a.chunk >= a.K) return;                          // an empty trailing chunk
     // (the integer division above runs on the VALU: make the uniformity of what the buffer descriptors are built from explicit)
-    q256_body<MODE == Q256_EPAIR, MODE == Q256_DIAG, RAGGED>(a, __builtin_amdgcn_readfirstlane(pa), __builtin_amdgcn_readfirstlane(pb),
+    q256_body<MODE == Q256_EPAIR, MODE == Q256_DIAG || MODE == Q256_HALF, RAGGED, MODE == Q256_HALF>(a, __builtin_amdgcn_readfirstlane(pa), __builtin_amdgcn_readfirstlane(pb),
                                                              __builtin_amdgcn_readfirstlane(chunk_id), zs0, zs1);
 }
 
@@ -355,8 +371,8 @@ struct Q256Plan { int nx, nt, npairs, nchunk; int64_t chunk; size_t part_bytes, 
 
 static Q256Plan plan_q256(int B, int64_t K) {
     Q256Plan pl{};
-    pl.nx = B / QP;
-    pl.nt = 2 * pl.nx;
+    pl.nx = B / QP;                                                          // 0 for B == 128: one panel [X ; E]
+    pl.nt = pl.nx ? 2 * pl.nx : 1;
     pl.npairs = pl.nt * (pl.nt + 1) / 2;
     const int64_t ngran = (K + QG - 1) / QG;
     // Number of K-chunks (a multiple of 8: one residue class per XCD); the three launches run pairs(mode) * n workgroups
@@ -373,7 +389,7 @@ static Q256Plan plan_q256(int B, int64_t K) {
     for (int64_t n = nmin; n <= 2 * nmin; n += 8) {
         const int64_t gpc = (ngran + n - 1) / n;
         int64_t rounds = 0;
-        for (int mode = 0; mode < 3; ++mode) rounds += ((int64_t)q256_mode_pairs(mode, pl.nx) * n + 255) / 256;
+        for (int mode = 0; mode < 4; ++mode) rounds += ((int64_t)q256_mode_pairs(mode, pl.nx) * n + 255) / 256;
         const double cost = (double)rounds * ((double)gpc + 3.0);           // + the fixed cost of a workgroup (its 256 KB tile, ramp-up)
         if (cost < best_cost - 1e-9) { best_cost = cost; best = (int)n; }
     }
@@ -381,13 +397,13 @@ static Q256Plan plan_q256(int B, int64_t K) {
     pl.chunk = ((ngran + best - 1) / best) * QG;
     pl.part_bytes = align_up((size_t)pl.npairs * pl.nchunk * QELEMS * sizeof(float), 256);
     pl.gsum_bytes = align_up((size_t)pl.npairs * QELEMS * sizeof(double), 256);
-    pl.e_bytes = align_up((size_t)B * K * sizeof(float), 256);
+    pl.e_bytes = pl.nx ? align_up((size_t)B * K * sizeof(float), 256) : 0;    // the single-panel form never writes E
     pl.ws_bytes = pl.part_bytes + pl.gsum_bytes + pl.e_bytes;
     return pl;
 }
 
 static bool q256_shape_ok(int B, int64_t K) {
-    return B >= QP && B % QP == 0 && B <= 4096 && K % 4 == 0 && K >= 256 && K <= (1 << 22);   // K: 32-bit panel offsets
+    return (B == QP / 2 || (B >= QP && B % QP == 0)) && B <= 4096 && K % 4 == 0 && K >= 256 && K <= (1 << 22);   // K: 32-bit panel offsets
 }
 
 void gram_q256_sums_span(int B, int64_t K, size_t* off, size_t* n) {
@@ -422,7 +438,7 @@ int run_gram_q256(const CostBatch& cb, int64_t K, float sc, int T, int J, void* 
     if (stage != 2) {
         Q256Args qa{cb.p[0].x, cb.p[0].y, e, B, pl.nx, pl.nt, pl.nchunk, K, pl.chunk, part};
         const bool ragged = K % QG != 0;
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             const int np = q256_mode_pairs(mode, pl.nx);
             if (np == 0) continue;
             const dim3 grid(np * pl.nchunk), block(256);
@@ -432,6 +448,9 @@ int run_gram_q256(const CostBatch& cb, int64_t K, float sc, int T, int J, void* 
             } else if (mode == Q256_DIAG) {
                 if (ragged) hipLaunchKernelGGL((gram_q256<Q256_DIAG, true>), grid, block, 0, st, qa);
                 else hipLaunchKernelGGL((gram_q256<Q256_DIAG, false>), grid, block, 0, st, qa);
+            } else if (mode == Q256_HALF) {
+                if (ragged) hipLaunchKernelGGL((gram_q256<Q256_HALF, true>), grid, block, 0, st, qa);
+                else hipLaunchKernelGGL((gram_q256<Q256_HALF, false>), grid, block, 0, st, qa);
             } else {
                 if (ragged) hipLaunchKernelGGL((gram_q256<Q256_OFF, true>), grid, block, 0, st, qa);
                 else hipLaunchKernelGGL((gram_q256<Q256_OFF, false>), grid, block, 0, st, qa);

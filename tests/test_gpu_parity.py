@@ -441,10 +441,11 @@ def _cost3_oracle(real, fake, f):
     return out
 
 
-@pytest.mark.parametrize("B,K", [(256, 2560), (256, 2560 + 36), (512, 3072 + 4), (768, 1536)])
+@pytest.mark.parametrize("B,K", [(256, 2560), (256, 2560 + 36), (512, 3072 + 4), (768, 1536), (128, 2560 + 36), (128, 4096)])
 def test_tile256_gram_against_the_128_row_tiles_the_direct_kernel_and_the_oracle(G, L, B, K):
-    """B % 256 == 0: the 256-row pair tiles (cost_tile256.hip: E written by the (X_i, E_i) pairs, triangular tile map on
-    diagonal pairs, one K-chunk per partial tile) against the 128-row tiles they replace (option "cost_tile256" = 0), the
+    """B % 256 == 0 and B == 128 (the stack [X ; E] is ONE 256-row panel, E formed while staging): the 256-row pair tiles
+    (cost_tile256.hip: E written by the (X_i, E_i) pairs, triangular tile map on diagonal pairs, one K-chunk per partial
+    tile) against the 128-row tiles they replace (option "cost_tile256" = 0), the
     direct-difference kernel and the fp64 oracle -- K a multiple of 32, K % 32 != 0 (the RAGGED instantiation: last granule
     partial), a single chunk, six panels."""
     real, fake, f = _tile_inputs(B, K, 2000 + B + K)
