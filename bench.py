@@ -130,6 +130,71 @@ def time_cost_kernel(t, reps=200):
     return out, K, C3
 
 
+def pmc_child():
+    """`bench.py --pmc-child`: nothing but 20 launches of the dominant cost kernel (KCCOT_COST_PARTIAL_ONLY) at configs[1],
+    for the counter passes of live_pmc_traffic()."""
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, ptr, stream_of, workspace, check
+    dev = torch.device("cuda", 0)
+    _, t = make_inputs(SHAPE["B"], 0, dev)
+    B = SHAPE["B"]
+    real, fake = t["real"].reshape(B, -1), t["fake"].reshape(B, -1)
+    K = real.shape[1]
+    T, J = t["h_fake"].shape[1], t["h_fake"].shape[2]
+    C3 = torch.empty(3, B, B, device=dev)
+    ws, wsb = workspace(lib.kccot_pairwise_cost3_workspace_bytes(B, K), real)
+    for _ in range(20):
+        check(lib.kccot_pairwise_cost3_f32(ptr(real), ptr(fake), B, K, SC, ptr(t["h_fake"]), ptr(t["h_real"]), ptr(t["m_real"]),
+                                           ptr(t["m_fake"]), T, J, _lib.COST_PARTIAL_ONLY, ptr(C3), ws, wsb, stream_of(real)),
+              "pairwise_cost3")
+    torch.cuda.synchronize()
+
+
+def live_pmc_traffic(kernel_prefix="gram128_partial", timeout_s=120):
+    """HBM-side bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two rocprofv3 passes (--pmc FETCH_SIZE, then
+    --pmc WRITE_SIZE -- one counter per pass, no trace domain besides the kernel trace, as MI355X_MICROARCH.md's HBM section
+    prescribes) over a child process that only launches that kernel; counters in KiB, FETCH_SIZE doubled (gfx950 counts a
+    wide coalesced read at half its bytes).  Returns (bytes, note) or (None, reason): any failure -- no rocprofv3, a
+    profiler already attached to this process, a timeout -- leaves the committed figure of profiles/hbm_traffic.json."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None, "this process already runs under a profiler"
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="kccot_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child"]
+            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                tail = " | ".join(r.stdout.decode(errors="replace").strip().splitlines()[-3:])
+                return None, "rocprofv3 --pmc %s exited with %d: %s" % (counter, r.returncode, tail[-300:])
+            vals = []
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and kernel_prefix in row.get("Kernel_Name", ""):
+                        vals.append(float(row["Counter_Value"]) * 1024.0)
+            if not vals:
+                return None, "no %s rows for %s" % (counter, kernel_prefix)
+            per[counter] = (sum(vals) / len(vals), len(vals))
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 pass timed out after %d s" % timeout_s
+    except Exception as e:            # the bench line must not depend on the profiler
+        return None, "counter pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = 2.0 * per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
+    return fetch + write, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in two separate passes "
+                           "over %d + %d launches of a child process (bench.py --pmc-child), KiB units, FETCH_SIZE x2 (gfx950 "
+                           "wide-read correction): fetch %.2f MB + write %.2f MB"
+                           % (per["FETCH_SIZE"][1], per["WRITE_SIZE"][1], fetch / 1e6, write / 1e6))
+
+
 def time_sinkhorn(C3, L=100, reps=50):
     """The three-problem solve and its reverse sweep alone (every iteration executed: main sets the option
     "sinkhorn_shortcut" = 0): us per launch and per dependent half-step."""
@@ -368,7 +433,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the train-steps/sec child process")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs[2..4] block")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-measure roofline.traffic (two rocprofv3 counter passes "
+                                                          "over a child process); report the committed figure")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child()
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -548,6 +619,13 @@ def main():
             rec = json.load(open(tf))
             traffic = rec.get("gram128_partial_bytes_per_launch")
             traffic_source = rec.get("source", "profiles/hbm_traffic.json (committed rocprofv3 --pmc pass, not measured in this run)")
+        committed = traffic
+        if world == 1 and not args.no_pmc and not f32_path:
+            live, note = live_pmc_traffic()
+            if live:
+                traffic, traffic_source = live, note
+            else:
+                traffic_source = "%s [live counter pass skipped: %s]" % (traffic_source, note)
         hbm = alg_bytes / t_s / 1e9
         tfl = alg_flops / t_s / 1e12
         ideal_hbm_us = alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e6
@@ -580,6 +658,7 @@ def main():
                                                     "applies to the option gram_f32 = 1, secondary here"}}
         roof.update({"traffic": traffic, "traffic_source": traffic_source,
                      "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                     "traffic_committed_pass": committed,
                      "kernel_us": kt["partial"], "cost_stage_us": kt["stage"],
                      "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
                      "timing": "200 launches between two events on the launch stream"})

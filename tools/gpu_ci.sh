@@ -19,7 +19,7 @@ step pytest 900 python -m pytest tests -m gpu -q --tb=short --maxfail=40 -p no:c
 step smoke 300 python -c "import __graft_entry__ as g; g.smoke()"
 step bench 600 python bench.py --steps 50 --warmup 10
 export TMPDIR=/tmp
-step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-configs
+step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-configs --no-pmc
 find "$OUT/prof" -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} "$OUT/kernel_stats.csv"
 [ -f "$OUT/kernel_stats.csv" ] && head -n 25 "$OUT/kernel_stats.csv"
 exit 0

@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 export KCCOT_BENCH_EAGER=1
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$OUT/sq" -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-train --no-configs > "$OUT/sq.log" 2>&1 || { echo "pass failed"; tail -20 "$OUT/sq.log"; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$OUT/sq" -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-train --no-configs --no-pmc > "$OUT/sq.log" 2>&1 || { echo "pass failed"; tail -20 "$OUT/sq.log"; exit 1; }
 find "$OUT/sq" -name "*counter_collection.csv" | head -1 | xargs -r -I{} cp {} "$OUT/sq_counters.csv"
 python - "$OUT" <<'PY'
 import csv, sys, collections
