@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define KCCOT_VERSION 300          /* 0.3.0 */
+#define KCCOT_VERSION 301          /* 0.3.1 */
 #define KCCOT_EINVAL (-1)          /* bad shape / null pointer / inconsistent arguments      */
 #define KCCOT_EUNSUPPORTED (-2)    /* valid request outside what this build implements       */
 #define KCCOT_EWORKSPACE (-3)      /* workspace too small                                    */
@@ -160,6 +160,23 @@ int kccot_pairwise_cost3_rows_gram_f32(const float* real, const float* fake, int
                                        const float* m_fake, int T, int J, int row_begin, int row_count,
                                        const double* norms, float* C3_rows, void* ws, size_t ws_bytes,
                                        kccot_stream_t stream);
+
+/* The same in two stages, for a caller that receives the COLUMNS in pieces (kccotgan_amd/dist.py with
+ * KCCOT_DIST_GATHER_CHUNKS = N: the videos are all-gathered in N column ranges and each range's Gram sums are formed while
+ * the next ranges are still in flight -- SURVEY.md section 8(e) "chunk the gather along K"):
+ *   _sums_f64: real / fake are [B, K] arrays holding ONE column range of all samples (K = its width); the fp64 Gram sums of
+ *   the row block (kccot_pairwise_cost3_rows_gram_sums_count doubles) are written (accumulate = 0) or added to
+ *   (accumulate != 0); stream order fixes the order of the additions, so a fixed range order gives a reproducible result.
+ *   Workspace: kccot_pairwise_cost3_rows_gram_workspace_bytes(row_count, B, K) of that range.
+ *   _from_sums_f32: the three row blocks from the complete sums and the norms over ALL columns (kccot_row_norms_f64). */
+size_t kccot_pairwise_cost3_rows_gram_sums_count(int row_count, int B);
+int kccot_pairwise_cost3_rows_gram_sums_f64(const float* real, const float* fake, int B, int64_t K, int row_begin,
+                                            int row_count, double* gsum, int accumulate, void* ws, size_t ws_bytes,
+                                            kccot_stream_t stream);
+int kccot_pairwise_cost3_rows_gram_from_sums_f32(const double* gsum, int B, float sc, const float* h_fake,
+                                                 const float* h_real, const float* m_real, const float* m_fake, int T,
+                                                 int J, int row_begin, int row_count, const double* norms,
+                                                 float* C3_rows, kccot_stream_t stream);
 
 /* Backward of the three cost matrices: given g3 = dLoss/dC3 [3,B,B] writes
  *   dfake [B,K] (may be NULL), dh_fake, dh_real, dm_real, dm_fake [B,T,J] (each may be NULL).

@@ -69,4 +69,4 @@ from . import _lib            # noqa: F401,E402  (loads the HIP library)
 from . import gan_utils       # noqa: F401,E402
 from . import data_utils      # noqa: F401,E402
 
-__version__ = "0.3.0"
+__version__ = "0.3.1"

@@ -46,6 +46,9 @@ SIGNATURES = {
     "kccot_row_norms_workspace_bytes": (_sz, [_i]),
     "kccot_row_norms_f64": (_i, [_fp, _fp, _i, _i64, _fp, _fp, _sz, _fp]),
     "kccot_pairwise_cost3_rows_gram_f32": (_i, [_fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _sz, _fp]),
+    "kccot_pairwise_cost3_rows_gram_sums_count": (_sz, [_i, _i]),
+    "kccot_pairwise_cost3_rows_gram_sums_f64": (_i, [_fp, _fp, _i, _i64, _i, _i, _fp, _i, _fp, _sz, _fp]),
+    "kccot_pairwise_cost3_rows_gram_from_sums_f32": (_i, [_fp, _i, _f, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp]),
     "kccot_pairwise_cost3_bwd_workspace_bytes": (_sz, [_i, _i64]),
     "kccot_pairwise_cost3_bwd_f32": (_i, [_fp, _fp, _fp, _i, _i64, _f, _fp, _fp, _fp, _fp, _i, _i,
                                           _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),

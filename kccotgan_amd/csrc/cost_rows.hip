@@ -190,9 +190,10 @@ __global__ __launch_bounds__(256) void rows_gram(RowsArgs a) {
     }
 }
 
-// fp64 sum over the chunks, fixed order; eight loads in flight.  grid (elems / 256, panels)
+// fp64 sum over the chunks, fixed order; eight loads in flight.  grid (elems / 256, panels).  accumulate != 0: added to what
+// gsum holds (a caller that feeds the columns in several calls, kccot_pairwise_cost3_rows_gram_sums_f64).
 __global__ __launch_bounds__(256) void rows_gram_reduce(const float* __restrict__ part, int nstride, int nchunk, int elems,
-                                                        double* __restrict__ gsum) {
+                                                        double* __restrict__ gsum, int accumulate) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     const float* p = part + (int64_t)blockIdx.y * nstride * elems + e;
     double s = 0.0;
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(256) void rows_gram_reduce(const float* __restrict_
         for (int i = 0; i < 8; ++i) s += (double)v[i];
     }
     for (; c < nchunk; ++c) s += (double)p[(int64_t)c * elems];
-    gsum[(int64_t)blockIdx.y * elems + e] = s;
+    double* g = gsum + (int64_t)blockIdx.y * elems + e;
+    *g = accumulate ? *g + s : s;
 }
 
 struct RowsFin {
@@ -372,31 +374,11 @@ extern "C" int kccot_row_norms_f64(const float* real, const float* fake, int row
     return launch_row_norms(real, fake, rows, K, norms_out, scratch, (hipStream_t)stream);
 }
 
-extern "C" int kccot_pairwise_cost3_rows_gram_f32(const float* real, const float* fake, int B, int64_t K, float sc,
-                                                  const float* h_fake, const float* h_real, const float* m_real,
-                                                  const float* m_fake, int T, int J, int row_begin, int row_count,
-                                                  const double* norms, float* C3_rows, void* ws, size_t ws_bytes,
-                                                  kccot_stream_t stream) {
-    if (!real || !fake || !C3_rows) return fail(KCCOT_EINVAL, "pairwise_cost3_rows_gram: null pointer");
-    if (!h_fake || !h_real || !m_real || !m_fake) return fail(KCCOT_EINVAL, "pairwise_cost3_rows_gram: all four feature tensors are needed");
-    if (B <= 0 || K <= 0 || T < 1 || J < 1 || row_begin < 0 || row_count <= 0 || row_begin + row_count > B)
-        return fail(KCCOT_EINVAL, "pairwise_cost3_rows_gram: bad shape B=%d K=%lld rows [%d,%d)", B, (long long)K, row_begin,
-                    row_begin + row_count);
-    if (!rows_shape_ok(row_count, B, K) || ((uintptr_t)real | (uintptr_t)fake) % 16)
-        return fail(KCCOT_EUNSUPPORTED, "pairwise_cost3_rows_gram: needs 32 or 64 rows, B %% 128 == 0, K %% 4 == 0, 256 <= K <= 2^22 "
-                    "(kccot_pairwise_cost3_rows_gram_supported); use kccot_pairwise_cost3_rows_f32");
-    const RowsPlan pl = plan_rows(row_count, B, K);
-    if (!ws || ws_bytes < pl.ws_bytes)
-        return fail(KCCOT_EWORKSPACE, "pairwise_cost3_rows_gram: workspace %zu < required %zu", ws_bytes, pl.ws_bytes);
-    hipStream_t st = (hipStream_t)stream;
-    float* part = static_cast<float*>(ws);
-    double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.part_bytes);
-    double* own_norms = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.part_bytes + pl.gsum_bytes);
+// stage 1: the fp64 Gram sums of the row block over the K columns given (partial tiles + reduce); stage 2: the three cost
+// row blocks from the sums and the norms.  kccot_pairwise_cost3_rows_gram_f32 runs both.
+static int rows_gram_sums(const float* real, const float* fake, int B, int64_t K, int row_begin, int row_count, double* gsum,
+                          int accumulate, float* part, const RowsPlan& pl, hipStream_t st) {
     int rc;
-    if (!norms) {   // no gathered norms given: one pass over the whole batch (a single-process caller; the sharded one gathers them)
-        if ((rc = launch_row_norms(real, fake, B, K, own_norms, reinterpret_cast<double*>(part), st))) return rc;   // scratch: the partial-tile area, not in use yet
-        norms = own_norms;
-    }
     const bool ragged = K % QG != 0;
     const int nxx = B / RB, nmix = (B % RB) ? 1 : 0, nee = pl.npan - nxx - nmix;     // column panels: X X | X E | E E
     RowsArgs ra{real, fake, B, row_count, row_begin, 0, 0, pl.nchunk, K, pl.chunk, part};
@@ -417,8 +399,14 @@ extern "C" int kccot_pairwise_cost3_rows_gram_f32(const float* real, const float
         if ((rc = launch_status("rows_gram<ee>"))) return rc;
     }
     const int elems = pl.am * RB, nvalid = (int)((K + pl.chunk - 1) / pl.chunk);
-    hipLaunchKernelGGL(rows_gram_reduce, dim3(elems / 256, pl.npan), dim3(256), 0, st, (const float*)part, pl.nchunk, nvalid, elems, gsum);
-    if ((rc = launch_status("rows_gram_reduce"))) return rc;
+    hipLaunchKernelGGL(rows_gram_reduce, dim3(elems / 256, pl.npan), dim3(256), 0, st, (const float*)part, pl.nchunk, nvalid, elems, gsum,
+                       accumulate);
+    return launch_status("rows_gram_reduce");
+}
+
+static int rows_gram_from_sums(const double* gsum, int B, float sc, const float* h_fake, const float* h_real, const float* m_real,
+                               const float* m_fake, int T, int J, int row_begin, int row_count, const double* norms,
+                               float* C3_rows, hipStream_t st) {
     const int64_t rb = (int64_t)row_count * B, tj = (int64_t)T * J;
     RowsFin f{};
     f.gsum = gsum; f.norms = norms; f.B = B; f.m = row_count; f.row_begin = row_begin; f.sc = sc; f.T = T; f.J = J;
@@ -428,4 +416,72 @@ extern "C" int kccot_pairwise_cost3_rows_gram_f32(const float* real, const float
     f.M[0] = m_real; f.M[1] = m_real; f.M[2] = m_fake;
     hipLaunchKernelGGL(rows_gram_finalize, dim3(B / CAUSAL_TILE, row_count / CAUSAL_TILE, 3), dim3(256), 0, st, f);
     return launch_status("rows_gram_finalize");
+}
+
+static int rows_gram_check(const char* who, const float* real, const float* fake, int B, int64_t K, int row_begin, int row_count) {
+    if (!real || !fake) return fail(KCCOT_EINVAL, "%s: null pointer", who);
+    if (B <= 0 || K <= 0 || row_begin < 0 || row_count <= 0 || row_begin + row_count > B)
+        return fail(KCCOT_EINVAL, "%s: bad shape B=%d K=%lld rows [%d,%d)", who, B, (long long)K, row_begin, row_begin + row_count);
+    if (!rows_shape_ok(row_count, B, K) || ((uintptr_t)real | (uintptr_t)fake) % 16)
+        return fail(KCCOT_EUNSUPPORTED, "%s: needs 32 or 64 rows, B %% 128 == 0, K %% 4 == 0, 256 <= K <= 2^22 "
+                    "(kccot_pairwise_cost3_rows_gram_supported); use kccot_pairwise_cost3_rows_f32", who);
+    return 0;
+}
+
+extern "C" int kccot_pairwise_cost3_rows_gram_f32(const float* real, const float* fake, int B, int64_t K, float sc,
+                                                  const float* h_fake, const float* h_real, const float* m_real,
+                                                  const float* m_fake, int T, int J, int row_begin, int row_count,
+                                                  const double* norms, float* C3_rows, void* ws, size_t ws_bytes,
+                                                  kccot_stream_t stream) {
+    int rc = rows_gram_check("pairwise_cost3_rows_gram", real, fake, B, K, row_begin, row_count);
+    if (rc) return rc;
+    if (!C3_rows) return fail(KCCOT_EINVAL, "pairwise_cost3_rows_gram: null pointer");
+    if (!h_fake || !h_real || !m_real || !m_fake) return fail(KCCOT_EINVAL, "pairwise_cost3_rows_gram: all four feature tensors are needed");
+    if (T < 1 || J < 1) return fail(KCCOT_EINVAL, "pairwise_cost3_rows_gram: bad feature shape T=%d J=%d", T, J);
+    const RowsPlan pl = plan_rows(row_count, B, K);
+    if (!ws || ws_bytes < pl.ws_bytes)
+        return fail(KCCOT_EWORKSPACE, "pairwise_cost3_rows_gram: workspace %zu < required %zu", ws_bytes, pl.ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = static_cast<float*>(ws);
+    double* gsum = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.part_bytes);
+    double* own_norms = reinterpret_cast<double*>(static_cast<char*>(ws) + pl.part_bytes + pl.gsum_bytes);
+    if (!norms) {   // no gathered norms given: one pass over the whole batch (a single-process caller; the sharded one gathers them)
+        if ((rc = launch_row_norms(real, fake, B, K, own_norms, reinterpret_cast<double*>(part), st))) return rc;   // scratch: the partial-tile area, not in use yet
+        norms = own_norms;
+    }
+    if ((rc = rows_gram_sums(real, fake, B, K, row_begin, row_count, gsum, 0, part, pl, st))) return rc;
+    return rows_gram_from_sums(gsum, B, sc, h_fake, h_real, m_real, m_fake, T, J, row_begin, row_count, norms, C3_rows, st);
+}
+
+// The same in two stages for a caller that receives the COLUMNS in pieces (a batch-sharded caller that all-gathers the
+// videos in K-chunks and overlaps the transfers with this accumulation): `real` / `fake` are [B, K] arrays of ONE column
+// range of all samples; the fp64 sums of the ranges add up (accumulate = 0 for the first range, 1 afterwards; stream order
+// fixes the order of the additions).  The row norms must cover ALL columns (they are gathered separately).
+extern "C" size_t kccot_pairwise_cost3_rows_gram_sums_count(int row_count, int B) {
+    if (!(row_count == 32 || row_count == 64) || B < 128 || B % 128) return 0;
+    return (size_t)((2 * B + RB - 1) / RB) * (2 * row_count) * RB;
+}
+
+extern "C" int kccot_pairwise_cost3_rows_gram_sums_f64(const float* real, const float* fake, int B, int64_t K, int row_begin,
+                                                       int row_count, double* gsum, int accumulate, void* ws, size_t ws_bytes,
+                                                       kccot_stream_t stream) {
+    int rc = rows_gram_check("pairwise_cost3_rows_gram_sums", real, fake, B, K, row_begin, row_count);
+    if (rc) return rc;
+    if (!gsum) return fail(KCCOT_EINVAL, "pairwise_cost3_rows_gram_sums: null pointer");
+    const RowsPlan pl = plan_rows(row_count, B, K);
+    if (!ws || ws_bytes < pl.part_bytes)
+        return fail(KCCOT_EWORKSPACE, "pairwise_cost3_rows_gram_sums: workspace %zu < required %zu", ws_bytes, pl.part_bytes);
+    return rows_gram_sums(real, fake, B, K, row_begin, row_count, gsum, accumulate, static_cast<float*>(ws), pl, (hipStream_t)stream);
+}
+
+extern "C" int kccot_pairwise_cost3_rows_gram_from_sums_f32(const double* gsum, int B, float sc, const float* h_fake,
+                                                            const float* h_real, const float* m_real, const float* m_fake,
+                                                            int T, int J, int row_begin, int row_count, const double* norms,
+                                                            float* C3_rows, kccot_stream_t stream) {
+    if (!gsum || !norms || !C3_rows || !h_fake || !h_real || !m_real || !m_fake)
+        return fail(KCCOT_EINVAL, "pairwise_cost3_rows_gram_from_sums: null pointer");
+    if (!(row_count == 32 || row_count == 64) || B < 128 || B % 128 || row_begin < 0 || row_begin + row_count > B || T < 1 || J < 1)
+        return fail(KCCOT_EINVAL, "pairwise_cost3_rows_gram_from_sums: bad shape B=%d rows [%d,%d) T=%d J=%d", B, row_begin,
+                    row_begin + row_count, T, J);
+    return rows_gram_from_sums(gsum, B, sc, h_fake, h_real, m_real, m_fake, T, J, row_begin, row_count, norms, C3_rows, (hipStream_t)stream);
 }

@@ -91,6 +91,24 @@ class HipOps:
         return out
 
     @staticmethod
+    def rows_gram_sums(real_c, fake_c, row_begin, row_count, gsum, accumulate):
+        """fp64 Gram sums of the rank's row block over ONE column range (real_c, fake_c: [B, Kc] of all samples), written to
+        or added to `gsum` (kccot_pairwise_cost3_rows_gram_sums_f64)."""
+        B, Kc = real_c.shape
+        ws, wsb = workspace(lib.kccot_pairwise_cost3_rows_gram_workspace_bytes(row_count, B, Kc), real_c)
+        check(lib.kccot_pairwise_cost3_rows_gram_sums_f64(ptr(real_c), ptr(fake_c), B, Kc, row_begin, row_count, ptr(gsum),
+                                                          1 if accumulate else 0, ws, wsb, stream_of(real_c)), "rows_gram_sums")
+
+    @staticmethod
+    def rows_gram_from_sums(gsum, B, h_fake, h_real, m_real, m_fake, sc, row_begin, row_count, norms):
+        T, J = h_fake.shape[1], h_fake.shape[2]
+        out = _lib.empty((3, row_count, B), torch.float32, gsum.device)
+        check(lib.kccot_pairwise_cost3_rows_gram_from_sums_f32(ptr(gsum), B, sc, ptr(h_fake), ptr(h_real), ptr(m_real), ptr(m_fake),
+                                                               T, J, row_begin, row_count, ptr(norms.contiguous()), ptr(out),
+                                                               stream_of(gsum)), "rows_gram_from_sums")
+        return out
+
+    @staticmethod
     def replicate_costs(B, K):
         """Batches of at most 64: every rank assembles the WHOLE [3,B,B] with the one-pass MFMA kernels (31 us at
         configs[1]) instead of its row block on the direct kernel (46-100 us) followed by another all-gather --
@@ -320,6 +338,42 @@ def all_gather_cat(t, group=None):
     return out
 
 
+def gather_chunk_bounds(K, nchunks):
+    """Column ranges of the chunked video all-gather (KCCOT_DIST_GATHER_CHUNKS): `nchunks` ranges of whole 32-column load
+    granules (the last one takes the remainder), every range at least 256 columns wide.  A function of (K, nchunks) only, so
+    all ranks cut alike."""
+    gran = (K + 31) // 32
+    n = max(1, min(int(nchunks), gran // 8))
+    per = (gran + n - 1) // n
+    bounds, a = [], 0
+    while a < K:
+        b = min(K, a + per * 32)
+        if K - b < 256:
+            b = K
+        bounds.append((a, b))
+        a = b
+    return bounds
+
+
+def _gather_columns_async(t_l, bounds, group):
+    """all-gather the column ranges of a [Bl, K] shard as separate collectives: [(work or None, [B, Kc] tensor)] in range
+    order.  RCCL: async_op -- the collectives queue up on the communicator's stream and `work.wait()` makes the compute
+    stream wait for ONE of them, so what is computed on range c overlaps the transfers of ranges c + 1, ...; gloo (CPU
+    rehearsal with device tensors): staged through the host, no overlap."""
+    world = dist.get_world_size(group)
+    out = []
+    for a, b in bounds:
+        piece = t_l[:, a:b].contiguous()
+        if world == 1:
+            out.append((None, piece))
+        elif dist.get_backend(group) == "gloo":
+            out.append((None, all_gather_cat(piece, group)))
+        else:
+            full = torch.empty((world * piece.shape[0], b - a), dtype=piece.dtype, device=piece.device)
+            out.append((dist.all_gather_into_tensor(full, piece, group=group, async_op=True), full))
+    return out
+
+
 class _AllGatherLocalGrad(torch.autograd.Function):
     """all-gather whose backward hands back the LOCAL slice of the incoming gradient.  For a
     quantity every rank computes identically from the gathered tensor (replicated loss) that slice
@@ -352,12 +406,37 @@ class _ShardedLoss(torch.autograd.Function):
         if (hasattr(ops, "row_norms") and not ops.replicate_costs(Bl * world, real_l.shape[1])
                 and ops.rows_gram_supported(Bl, Bl * world, real_l.shape[1]) and os.environ.get("KCCOT_DIST_ROWS") != "direct"):
             norms = all_gather_cat(ops.row_norms(real_l, fake_l), group)
-        real = all_gather_cat(real_l, group)
-        fake = all_gather_cat(fake_l, group)
+        # KCCOT_DIST_GATHER_CHUNKS = N > 1 (matrix-pipe row blocks only): the videos travel as N column ranges and the Gram
+        # sums of a range are formed while the later ranges are still in flight (opt-in: it has not
+        # been timed on more than one GPU).  The ranges are kept as they arrive -- the backward works range by range too.
+        nchunks = int(os.environ.get("KCCOT_DIST_GATHER_CHUNKS", "0") or 0)
+        chunked = norms is not None and nchunks > 1 and hasattr(ops, "rows_gram_sums")
+        bounds = gather_chunk_bounds(real_l.shape[1], nchunks) if chunked else None
+        chunked = chunked and len(bounds) > 1
+        if chunked:
+            pieces_r = _gather_columns_async(real_l, bounds, group)
+            pieces_f = _gather_columns_async(fake_l, bounds, group)
+            real = fake = None
+        else:
+            real = all_gather_cat(real_l, group)
+            fake = all_gather_cat(fake_l, group)
         # the four [Bl,T,J] feature shards travel as one message
         feats = all_gather_cat(torch.stack([h_fake_l, h_real_l, m_real_l, m_fake_l], dim=1), group)
         h_fake, h_real, m_real, m_fake = (feats[:, i].contiguous() for i in range(4))
-        if hasattr(ops, "cost3_full") and ops.replicate_costs(real.shape[0], real.shape[1]):
+        if chunked:
+            B = Bl * world
+            gsum = _lib.empty((int(lib.kccot_pairwise_cost3_rows_gram_sums_count(Bl, B)),), torch.float64, real_l.device)
+            real, fake = [], []
+            for c, ((wr, r_c), (wf, f_c)) in enumerate(zip(pieces_r, pieces_f)):      # fixed range order: reproducible sums
+                for w in (wr, wf):
+                    if w is not None:
+                        w.wait()
+                ops.rows_gram_sums(r_c, f_c, rank * Bl, Bl, gsum, c > 0)
+                real.append(r_c)
+                fake.append(f_c)
+            blk = ops.rows_gram_from_sums(gsum, B, h_fake, h_real, m_real, m_fake, sc, rank * Bl, Bl, norms)
+            C3 = all_gather_cat(blk.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()  # [3,B,B]
+        elif hasattr(ops, "cost3_full") and ops.replicate_costs(real.shape[0], real.shape[1]):
             C3 = ops.cost3_full(real, fake, h_fake, h_real, m_real, m_fake, sc)     # small batch: replicated assembly
         else:
             # row blocks of the three cost matrices (gan_utils.py:221-223)
@@ -394,7 +473,13 @@ class _ShardedLoss(torch.autograd.Function):
         else:
             gcost3 = torch.stack([2.0 * g, -g, -g])             # d(2 xy - xx - yy)
             dC3 = ops.sinkhorn3_bwd(saved, gcost3)
-        dfake, dhf, dhr, dmr, dmf = ops.cost3_bwd_rows(dC3, real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, Bl)
+        if isinstance(real, list):       # chunked gather: the video gradient is separable in the columns, range by range
+            parts = [ops.cost3_bwd_rows(dC3, r_c, f_c, h_fake, h_real, m_real, m_fake, sc, row_begin, Bl)
+                     for r_c, f_c in zip(real, fake)]
+            dfake = torch.cat([p[0] for p in parts], dim=1)
+            dhf, dhr, dmr, dmf = parts[0][1:]                    # the feature gradients do not depend on the videos
+        else:
+            dfake, dhf, dhr, dmr, dmf = ops.cost3_bwd_rows(dC3, real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, Bl)
         return None, dfake, dhf, dhr, dmr, dmf, None, None, None, None, None
 
 

@@ -22,6 +22,8 @@ bit-identical (tests/test_gpu_parity.py::test_graphed_loss_is_bit_identical).
 All require fixed shapes; inputs are copied into the static buffers on every call unless the
 caller writes into ``.static`` directly.
 """
+import os
+
 import torch
 
 from . import gan_utils
@@ -122,6 +124,13 @@ class GraphedShardedStep:
         self._cfg = (float(scaling_coef), float(epsilon), int(L), self.rank * Bl, Bl)
         # small batches: replicated one-pass cost assembly, no row-block exchange -- ONE graph after the input gathers
         self.replicated = kd.HipOps.replicate_costs(B, K)
+        # B > 64: the row block runs on the matrix pipe when the shape allows it (as dist._ShardedLoss does) and needs the
+        # row norms of every sample: each rank's own rows are computed in front of the gathers and travel with them
+        self.use_norms = (not self.replicated and kd.HipOps.rows_gram_supported(Bl, B, K)
+                          and os.environ.get("KCCOT_DIST_ROWS") != "direct")
+        if self.use_norms:
+            self.local["norms"] = torch.zeros((Bl, 3), dtype=torch.float64, device=dev)
+            self.full["norms"] = torch.zeros((B, 3), dtype=torch.float64, device=dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                        # warm-up off the capture: workspaces, ticket, allocator
@@ -154,6 +163,9 @@ class GraphedShardedStep:
             out.copy_(self._kd.all_gather_cat(local, self.group))
 
     def _gather_inputs(self):
+        if self.use_norms:
+            self.local["norms"].copy_(self._kd.HipOps.row_norms(self.local["real"], self.local["fake"]))
+            self._gather(self.full["norms"], self.local["norms"])
         # RCCL: the three all-gathers as ONE coalesced group (one launch, one set of fixed latencies); decided at the
         # first call, sequential calls if this torch build has no coalesced all-gather
         if self._nccl and getattr(self, "_coalesce", True):
@@ -177,7 +189,8 @@ class GraphedShardedStep:
         if self.replicated:
             self._C3 = self._kd.HipOps.cost3_full(self.full["real"], self.full["fake"], *self._f, sc)
             return
-        blk = self._kd.HipOps.cost3_rows(self.full["real"], self.full["fake"], *self._f, sc, row_begin, Bl)
+        blk = self._kd.HipOps.cost3_rows(self.full["real"], self.full["fake"], *self._f, sc, row_begin, Bl,
+                                         self.full["norms"] if self.use_norms else None)
         self._blk_t.copy_(blk.transpose(0, 1))
 
     def _seg_b(self):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_lib.lib, s), "libkccot.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
-    assert _lib.lib.kccot_version() == 300
+    assert _lib.lib.kccot_version() == 301
 
 
 def test_argument_validation_happens_before_any_launch():

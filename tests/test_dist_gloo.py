@@ -139,15 +139,17 @@ def test_data_parallel_trainer_keeps_replicas_identical(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("protocol", ["auto", "gather", "gather_direct"])
+@pytest.mark.parametrize("protocol", ["auto", "gather", "gather_direct", "gather_chunks"])
 def test_sharded_hip_batch_128(protocol, tmp_path):
     """Two ranks at B = 128 (64 samples each): `auto` picks the contraction-sharded protocol above 64 samples; `gather`
     builds the row blocks on the matrix pipe (Gram row block + all-gathered row norms, csrc/cost_rows.hip);
-    `gather_direct` keeps them on the direct-difference kernel (KCCOT_DIST_ROWS=direct); all against the single-GPU loss
-    and gradients."""
+    `gather_direct` keeps them on the direct-difference kernel (KCCOT_DIST_ROWS=direct); `gather_chunks` all-gathers the
+    videos in three column ranges and accumulates the Gram sums range by range (KCCOT_DIST_GATHER_CHUNKS=3; the backward
+    works range by range too); all against the single-GPU loss and gradients."""
     from kccotgan_amd import gan_utils as G
     shape, seed, regime = "deci128", 0, "near"
-    env = {"KCCOT_DIST_PROTOCOL": "gather", "KCCOT_DIST_ROWS": "direct"} if protocol == "gather_direct" else {"KCCOT_DIST_PROTOCOL": protocol}
+    env = {"gather_direct": {"KCCOT_DIST_PROTOCOL": "gather", "KCCOT_DIST_ROWS": "direct"},
+           "gather_chunks": {"KCCOT_DIST_PROTOCOL": "gather", "KCCOT_DIST_GATHER_CHUNKS": "3"}}.get(protocol, {"KCCOT_DIST_PROTOCOL": protocol})
     res = launch(2, shape, seed, regime, "cuda:0", "hip", tmp_path, env=env)
     inp = cases.gen_inputs(shape, seed, regime)
     t = {k: torch.from_numpy(v).to("cuda:0") for k, v in inp.items()}
@@ -163,6 +165,8 @@ def test_sharded_hip_batch_128(protocol, tmp_path):
             g = g.cpu().double().numpy()
             np.testing.assert_allclose(out["d" + k].reshape(Bl, -1), g.reshape(B, -1)[r * Bl:(r + 1) * Bl], rtol=0,
                                        atol=2e-3 * np.abs(g).max(), err_msg=k)
+        if protocol in ("gather", "gather_direct"):     # the graph-captured step runs the same kernels on the same operands
+            assert bool(out["graphed_loss_equal"]) and bool(out["graphed_grads_equal"]) and bool(out["graphed_sees_new_inputs"])
 
 
 def test_data_parallel_trainer_draws_different_noise_per_rank(tmp_path):

@@ -471,6 +471,27 @@ def test_tile256_gram_against_the_128_row_tiles_the_direct_kernel_and_the_oracle
         np.testing.assert_allclose(d, d.T, rtol=0, atol=2e-6 * np.abs(d).max())
 
 
+def test_rows_gram_in_column_ranges_equals_the_one_call_form(G, L):
+    """kccot_pairwise_cost3_rows_gram_sums_f64 / _from_sums_f32 (the chunked all-gather of the batch-sharded caller: the
+    Gram sums of a rank's row block accumulated over column ranges) against the one-call form on the whole K, at the cut
+    kccotgan_amd.dist.gather_chunk_bounds makes -- fp64 sums of disjoint column ranges in a fixed order: equal to fp64
+    rounding of sums whose fp32 partial tiles are cut at other columns (1e-6 of max|C|)."""
+    from kccotgan_amd import _lib
+    from kccotgan_amd.dist import HipOps as H, gather_chunk_bounds
+    B, K, rows = 256, 4096 + 36, 64
+    real, fake, f = _tile_inputs(B, K, 8123)
+    norms = H.row_norms(real, fake)
+    bounds = gather_chunk_bounds(K, 4)
+    assert len(bounds) == 4 and bounds[0][0] == 0 and bounds[-1][1] == K and all(a % 32 == 0 and b - a >= 256 for a, b in bounds)
+    for r0 in (0, 128):
+        ref = H.cost3_rows(real, fake, f[0], f[1], f[2], f[3], cases.SC, r0, rows, norms).cpu().numpy()
+        gsum = torch.full((int(_lib.lib.kccot_pairwise_cost3_rows_gram_sums_count(rows, B)),), float("nan"), dtype=torch.float64, device=DEV)
+        for c, (a, b) in enumerate(bounds):
+            H.rows_gram_sums(real[:, a:b].contiguous(), fake[:, a:b].contiguous(), r0, rows, gsum, c > 0)
+        got = H.rows_gram_from_sums(gsum, B, f[0], f[1], f[2], f[3], cases.SC, r0, rows, norms).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+
+
 def test_tiled_gram_128_row_tiles_with_materialised_difference_rows(G, L):
     """B = 640 (a multiple of 128 that is not one of 256, >= 512): the 128-row tiles with E = fake - real formed once
     (ediff_rows), ten panels, against the fp64 oracle."""
