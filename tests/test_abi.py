@@ -145,3 +145,27 @@ def test_option_table_is_the_only_run_time_switchboard():
             body = re.sub(r"#ifdef KCCOT_DIAG.*?#e(?:lse|ndif)", "", body, flags=re.S)
             hits += [(fn, m.group(0)) for m in re.finditer(r'getenv\("[A-Z_]+"\)', body)]
     assert hits == [("api.hip", 'getenv("KCCOT_OPTIONS")')], hits
+
+
+def test_header_is_plain_c_and_the_abi_works_from_c(tmp_path):
+    """include/kccot.h compiles as strict C99 (what a cgo / JNI / N-API stub includes), and a C program that dlopens the
+    library -- typed through the header's own declarations -- sees the documented behaviour of every entry point that
+    needs no GPU: version, the option table, error codes and the error string, workspace queries, argument checks."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    probe = tmp_path / "hdr.c"
+    probe.write_text('#include "kccot.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(probe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = tmp_path / "abi_smoke"
+    r = subprocess.run([gcc, "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-I", inc, "-o", str(exe),
+                        os.path.join(ROOT, "tests", "abi_smoke.c"), "-ldl"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe), os.path.join(ROOT, "kccotgan_amd", "csrc", "libkccot.so")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi_smoke ok" in r.stdout
