@@ -492,6 +492,27 @@ def test_rows_gram_in_column_ranges_equals_the_one_call_form(G, L):
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
 
 
+def test_c_abi_from_a_native_program(tmp_path):
+    """The drop-in boundary without Python or torch: tests/abi_gpu_smoke.cpp (hipMalloc, its own stream, nothing linked but
+    the HIP runtime and libkccot.so) calls kccot_sinkhorn_loss_{fwd,bwd}_f32 and checks the three cost matrices against a
+    double-precision host evaluation of gan_utils.py:14-17,34-38, the iteration counts, and the video gradient against a
+    central difference of the library's own loss along the gradient direction."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "kccotgan_amd", "csrc")
+    exe = str(tmp_path / "abi_gpu_smoke")
+    r = subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-I", os.path.join(root, "include"), "-o", exe,
+                        os.path.join(root, "tests", "abi_gpu_smoke.cpp"), "-L", libdir, "-lkccot", "-Wl,-rpath," + libdir],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "abi_gpu_smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_tiled_gram_128_row_tiles_with_materialised_difference_rows(G, L):
     """B = 640 (a multiple of 128 that is not one of 256, >= 512): the 128-row tiles with E = fake - real formed once
     (ediff_rows), ten panels, against the fp64 oracle."""
