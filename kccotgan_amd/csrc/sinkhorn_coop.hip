@@ -433,6 +433,22 @@ static int fault_injected() {
 #endif
 }
 
+// The exchange area is zeroed by a KERNEL whose stores have the scope of the exchange itself (relaxed, agent), not by
+// hipMemsetAsync: as a node of a captured graph the memset's zeros were not what the next node's agent-scope loads saw --
+// the first replay of a graph ran on fresh (zero) memory, every later one found the previous replay's tags, polled to its
+// bound and aborted to NaN (round 3: found when bench.py replayed the configs[3] step as a hipGraph; eager launches were
+// never affected).  tests/test_gpu_parity.py::test_multi_cu_sinkhorn_replays_as_a_graph.
+__global__ __launch_bounds__(256) void ll_zero(unsigned long long* __restrict__ w, int n64) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n64; i += gridDim.x * 256)
+        __hip_atomic_store(w + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static int ll_zero_area(void* p, size_t bytes, hipStream_t st) {      // bytes % 8 == 0 (CoopCtrl is 256 bytes, ll_word 8)
+    const int n64 = (int)(bytes / 8);
+    hipLaunchKernelGGL(ll_zero, dim3((n64 + 255) / 256 < 64 ? (n64 + 255) / 256 : 64), dim3(256), 0, st,
+                       static_cast<unsigned long long*>(p), n64);
+    return launch_status("ll_zero");
+}
+
 // flag-in-data kernels: ctrl | xu [nprob][n] words | xv | xcost [nprob][SC_MAXWG] words, zeroed as one block
 struct LLCarve { CoopCtrl* ctrl; ll_word* x0; ll_word* x1; ll_word* xc; size_t zero_bytes; float* second; };
 static LLCarve ll_carve(void* ws, int nprob, int n) {
@@ -451,7 +467,7 @@ int launch_sinkhorn_fwd_coop(const float* C, int nprob, int n, float eps, int L,
                              hipStream_t st) {
     const LLCarve lv = ll_carve(ws, nprob, n);
     if (lv.zero_bytes > sinkhorn_gen_workspace_bytes(nprob, n) / 2) return fail(KCCOT_EWORKSPACE, "sinkhorn_fwd(coop): exchange area");
-    if (hipMemsetAsync(lv.ctrl, 0, lv.zero_bytes, st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_fwd(coop): memset failed");
+    if (int zrc = ll_zero_area(lv.ctrl, lv.zero_bytes, st)) return zrc;
     const int nwg = (n + SC_LINES - 1) / SC_LINES;
     SinkLLArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
                  lv.ctrl, lv.x0, lv.x1, lv.xc, nwg, nprob, fault_injected()};
@@ -467,7 +483,7 @@ int launch_sinkhorn_bwd_coop(const float* C, const float* u_hist, const float* v
                              float eps, int L, const float* gcost, float* dC, void* ws, hipStream_t st) {
     const LLCarve lv = ll_carve(ws, nprob, n);
     if (lv.zero_bytes > sinkhorn_gen_workspace_bytes(nprob, n) / 2) return fail(KCCOT_EWORKSPACE, "sinkhorn_bwd(coop): exchange area");
-    if (hipMemsetAsync(lv.ctrl, 0, lv.zero_bytes, st) != hipSuccess) return fail(KCCOT_EINVAL, "sinkhorn_bwd(coop): memset failed");
+    if (int zrc = ll_zero_area(lv.ctrl, lv.zero_bytes, st)) return zrc;
     const int nwg = (n + SC_LINES - 1) / SC_LINES;
     SinkLLBwdArgs a{C, u_hist, v_hist, nits, gcost, dC, lv.second, n, L, eps, (float)(1.0 / (double)eps), lv.ctrl, lv.x0, lv.x1,
                     nwg, nprob};

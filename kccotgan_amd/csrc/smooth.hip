@@ -1253,6 +1253,11 @@ __global__ __launch_bounds__(256) void conv_axis_adjoint_if(const float* __restr
     }
 }
 
+// {1, 0, 0}: "maximum 1, no arg-max elements" for a plane kernel that runs a plain stencil.  A one-thread KERNEL, not
+// hipMemsetD32Async: memset nodes of a captured graph did not order with the kernel nodes around them on this stack (the
+// second replay of a captured 3-D backward read garbage scalars: NaN; round 3, tests: test_smoothing_replays_as_a_graph).
+__global__ void set_unit_scalars(float* __restrict__ s) { s[0] = 1.f; s[1] = 0.f; s[2] = 0.f; }
+
 static bool plane_eligible(int T, int W, int C, int radius, int naxes) {
     return naxes > 0 && (radius == 3 || radius == 4) && (int64_t)T * W * C <= 4096;
 }
@@ -1383,8 +1388,8 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
                 } else if (wrow) {
                     if ((rc = launch_wrow(out, tmp, n, W, C, radius, false, tp, st))) return rc;
                 } else {
-                    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x3f800000, 1, st) != hipSuccess)
-                        return fail(KCCOT_EINVAL, "smooth_fwd: memset failed");
+                    hipLaunchKernelGGL(set_unit_scalars, dim3(1), dim3(1), 0, st, one);
+                    if ((rc = launch_status("set_unit_scalars"))) return rc;
                     PlaneArgs pa{};
                     pa.in = out; pa.out = tmp; pa.mx = one; pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C;
                     pa.axes = KCCOT_SMOOTH_W; pa.tp = tp; pa.hseg = plane_hseg(B, H, false);
@@ -1567,9 +1572,8 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
                 if ((rc = launch_wrow(din, tmp, n, W, C, radius, true, tp, st))) return rc;
             } else {
                 float* one = scal + 4;                          // scalar slots behind {dot, ties}: {1, 0, 0}
-                if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x3f800000, 1, st) != hipSuccess ||
-                    hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one + 1), 0, 2, st) != hipSuccess)
-                    return fail(KCCOT_EINVAL, "smooth_bwd: memset failed");
+                hipLaunchKernelGGL(set_unit_scalars, dim3(1), dim3(1), 0, st, one);
+                if ((rc = launch_status("set_unit_scalars"))) return rc;
                 PlaneArgs pa{};
                 pa.in = din; pa.out_fwd = out; pa.out = tmp; pa.mx = one; pa.res = one + 1;   // max = 1, no ties: plain W^T
                 pa.B = B; pa.H = H; pa.T = T; pa.W = W; pa.C = C; pa.axes = KCCOT_SMOOTH_W; pa.tp = tp;

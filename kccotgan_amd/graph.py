@@ -32,19 +32,21 @@ _NAMES = ("real", "fake", "h_fake", "m_real", "h_real", "m_fake")
 _WRT = ("fake", "h_fake", "h_real", "m_real", "m_fake")
 
 
-def _loss(t, sc, sinkhorn_eps, sinkhorn_l):
+def _loss(t, sc, sinkhorn_eps, sinkhorn_l, honor_eps_l=False):
     return gan_utils.compute_sinkhorn_loss(t["real"], t["fake"], sc, sinkhorn_eps, sinkhorn_l, t["h_fake"], t["m_real"],
-                                           t["h_real"], t["m_fake"], video=True)
+                                           t["h_real"], t["m_fake"], video=True, honor_eps_l=honor_eps_l)
 
 
 class GraphedLossStep:
-    def __init__(self, sample, scaling_coef, sinkhorn_eps=0.8, sinkhorn_l=100, warmup=3):
+    def __init__(self, sample, scaling_coef, sinkhorn_eps=0.8, sinkhorn_l=100, warmup=3, honor_eps_l=False, clone=True):
         """``sample``: dict with the six tensors of compute_sinkhorn_loss (shapes and device are what
-        gets captured; values are copied)."""
-        self.static = {k: sample[k].detach().clone() for k in _NAMES}
+        gets captured; values are copied -- ``clone=False`` captures the given tensors themselves: a caller that owns
+        static buffers already, or a batch too large to hold twice).  ``honor_eps_l``: the keyword-only opt-in of
+        ``compute_sinkhorn_loss`` (the reference ignores ``sinkhorn_eps`` / ``sinkhorn_l``, gan_utils.py:221-223)."""
+        self.static = {k: (sample[k].detach().clone() if clone else sample[k].detach()) for k in _NAMES}
         for k in _WRT:
             self.static[k].requires_grad_(True)
-        self._cfg = (float(scaling_coef), sinkhorn_eps, sinkhorn_l)
+        self._cfg = (float(scaling_coef), sinkhorn_eps, sinkhorn_l, bool(honor_eps_l))
         dev = self.static["real"].device
         self._one = torch.ones((), device=dev)       # dLoss = 1 held in a static buffer: no fill kernel per replay
         side = torch.cuda.Stream(device=dev)

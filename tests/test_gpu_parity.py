@@ -492,6 +492,103 @@ def test_rows_gram_in_column_ranges_equals_the_one_call_form(G, L):
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
 
 
+def _capture(fn):
+    """Warm up on a side stream, capture `fn` into a hipGraph, return (graph, static outputs)."""
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream(DEV).wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    return g, out
+
+
+@pytest.mark.parametrize("n", [200, 256, 512])
+def test_multi_cu_sinkhorn_replays_as_a_graph(G, L, n):
+    """128 < n <= 1024: the multi-CU solve and reverse sweep captured into a hipGraph and replayed -- with a host sync after
+    every replay and back to back -- give the eager result bit for bit EVERY time.  (Round 3: the exchange area was zeroed
+    with hipMemsetAsync; as a graph node its zeros were not what the next node's agent-scope loads saw, so every replay
+    after the first polled to its bound and aborted to NaN.  It is zeroed by a kernel with agent-scope stores now.)"""
+    from kccotgan_amd.dist import HipOps as H
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    C3 = torch.rand((3, n, n), device=DEV, generator=gen) * 40
+    one = torch.ones((), device=DEV)
+
+    def step():
+        loss, saved = H.divergence_fwd(C3, 1.0, 100)
+        return loss, H.divergence_bwd(saved, one), saved[3]
+
+    with L.options(sinkhorn_shortcut=0):
+        l0, d0, n0 = step()
+        torch.cuda.synchronize()
+        assert n0[:3].tolist() == [100, 100, 100] and bool(torch.isfinite(d0).all())
+        g, (gl, gd, gn) = _capture(step)
+        for i in range(3):
+            g.replay()
+            torch.cuda.synchronize()
+            assert gn.tolist() == n0.tolist() and torch.equal(gl, l0) and torch.equal(gd, d0), ("synced replay", i)
+        for i in range(6):
+            g.replay()
+        torch.cuda.synchronize()
+        assert gn.tolist() == n0.tolist() and torch.equal(gl, l0) and torch.equal(gd, d0), "back-to-back replays"
+
+
+def test_graphed_loss_step_at_a_large_batch(G, L):
+    """GraphedLossStep at B = 256 (256-row Gram tiles, multi-CU Sinkhorn, one-launch video gradient): replays equal the
+    eager step bit for bit, repeatedly, and see new inputs."""
+    from kccotgan_amd.graph import GraphedLossStep
+    B, H_, T, W, C = 256, 8, 10, 8, 5
+    gen = torch.Generator(device=DEV).manual_seed(99)
+    t = {"real": torch.rand((B, H_, T, W, C), device=DEV, generator=gen)}
+    t["fake"] = (t["real"] + 0.05 * torch.randn(t["real"].shape, device=DEV, generator=gen)).clamp_(0, 1)
+    for k in ("h_fake", "m_real", "h_real", "m_fake"):
+        t[k] = torch.rand((B, T, 8), device=DEV, generator=gen)
+    names = ("fake", "h_fake", "h_real", "m_real", "m_fake")
+    for k in names:
+        t[k].requires_grad_(True)
+    loss = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"], t["m_fake"])
+    grads = torch.autograd.grad(loss, [t[k] for k in names])
+    gs = GraphedLossStep(t, cases.SC)
+    for i in range(4):
+        gl, gg = gs()
+        torch.cuda.synchronize()
+        assert torch.equal(gl.reshape(()), loss.detach().reshape(())), i
+        assert all(torch.equal(gg[k], g) for k, g in zip(names, grads)), i
+        assert gs.nits.tolist() == [100, 100, 100]
+    gl2, _ = gs(fake=t["fake"].detach() * 0.5)
+    torch.cuda.synchronize()
+    assert not torch.equal(gl2.reshape(()), loss.detach().reshape(())) and bool(torch.isfinite(gl2))
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 9, 10, 2), (2, 9, 30, 64, 1), (2, 6, 20, 16, 3)])
+def test_smoothing_replays_as_a_graph(L, shape):
+    """KernelSmoothing forward + backward (temporal and 3-D; the shapes take the LDS plane kernel with its memset scalars,
+    the lane-exchange walk, the any-channel kernels; statistics folded and not) captured and replayed three times."""
+    from kccotgan_amd.data_utils import KernelSmoothing
+    ks = KernelSmoothing(6, 6)
+    gen = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.rand(shape, device=DEV, generator=gen)
+    w = torch.randn(shape, device=DEV, generator=gen)
+    for fold in (0, 2):
+        with L.options(smooth_bwd_fold=fold):
+            for fn in (ks.temporal_convolution, ks.gaussian_convolution3D):
+                def step():
+                    xi = x.detach().requires_grad_(True)
+                    y = fn(xi, 2.0)
+                    (gx,) = torch.autograd.grad(y, xi, w)
+                    return y.detach(), gx
+                y0, g0 = step()
+                torch.cuda.synchronize()
+                g, (gy, gg) = _capture(step)
+                for i in range(3):
+                    g.replay()
+                    torch.cuda.synchronize()
+                    assert torch.equal(gy, y0) and torch.equal(gg, g0), (shape, fold, fn.__name__, i)
+
+
 def test_c_abi_from_a_native_program(tmp_path):
     """The drop-in boundary without Python or torch: tests/abi_gpu_smoke.cpp (hipMalloc, its own stream, nothing linked but
     the HIP runtime and libkccot.so) calls kccot_sinkhorn_loss_{fwd,bwd}_f32 and checks the three cost matrices against a
