@@ -21,6 +21,7 @@ SHAPES = {
     "cfg1": (8, 64, 20, 64, 1, 8),      # BASELINE configs[0]
     "cfg2": (64, 64, 30, 64, 1, 8),     # BASELINE configs[1]
     "deci128": (128, 8, 10, 8, 4, 8),   # config-3 batch, decimated frames (K = 2560): multi-rank tests only, no golden file
+    "deci256": (256, 8, 10, 8, 4, 8),   # config-4 batch, decimated frames: multi-rank tests only (n = 256: the multi-CU Sinkhorn)
 }
 
 # (shape name, seed, regime)

@@ -169,6 +169,32 @@ def test_sharded_hip_batch_128(protocol, tmp_path):
             assert bool(out["graphed_loss_equal"]) and bool(out["graphed_grads_equal"]) and bool(out["graphed_sees_new_inputs"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("protocol", ["gather", "ksplit"])
+def test_sharded_hip_batch_256_with_graph_replay(protocol, tmp_path):
+    """Two ranks at B = 256: n = 256 runs the multi-CU Sinkhorn (two processes' 48-workgroup solves side by side on the one
+    card), eagerly and inside the graph-captured steps (GraphedShardedStep / GraphedKSplitStep replayed twice: the second
+    replay is the one that broke before the library stopped using memset nodes), against the single-GPU loss and gradients."""
+    from kccotgan_amd import gan_utils as G
+    shape, seed, regime = "deci256", 0, "near"
+    res = launch(2, shape, seed, regime, "cuda:0", "hip", tmp_path, env={"KCCOT_DIST_PROTOCOL": protocol})
+    inp = cases.gen_inputs(shape, seed, regime)
+    t = {k: torch.from_numpy(v).to("cuda:0") for k, v in inp.items()}
+    for k in NAMES:
+        t[k].requires_grad_(True)
+    ref = G.compute_sinkhorn_loss(t["real"], t["fake"], cases.SC, 0.8, 100, t["h_fake"], t["m_real"], t["h_real"], t["m_fake"])
+    grads = torch.autograd.grad(ref, [t[k] for k in NAMES])
+    B = inp["real"].shape[0]
+    Bl = B // 2
+    for r, out in enumerate(res):
+        assert abs(float(out["loss"]) - float(ref.detach())) <= 5e-6 * abs(float(ref.detach()))
+        for k, g in zip(NAMES, grads):
+            g = g.cpu().double().numpy()
+            np.testing.assert_allclose(out["d" + k].reshape(Bl, -1), g.reshape(B, -1)[r * Bl:(r + 1) * Bl], rtol=0,
+                                       atol=2e-3 * np.abs(g).max(), err_msg=k)
+        assert bool(out["graphed_loss_equal"]) and bool(out["graphed_grads_equal"]) and bool(out["graphed_sees_new_inputs"])
+
+
 def test_data_parallel_trainer_draws_different_noise_per_rank(tmp_path):
     """Default seed on both ranks: the constructor broadcasts rank 0's weights (identical replicas) and then
     reseeds per rank, so the shards of the global batch are generated from DIFFERENT z (kernel_train.py:220,260
