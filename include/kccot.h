@@ -80,6 +80,10 @@ const char* kccot_last_error(void);
  *   sinkhorn_fused_max_n      64       largest n the fused solve + sweep launch accepts (<= 128; above 64 it spills registers)
  *   sinkhorn_lanes_per_line   0        4 / 8 / 16 lanes per matrix line for 32 < n <= 64 (0: forward 8, reverse sweep 16)
  *   sinkhorn_coop             1        0: 128 < n <= 1024 on the one-workgroup streaming solver instead of the multi-CU one
+ *   sinkhorn_coop_xcd         1        1: the multi-CU solver lays one problem out per XCD (1-D grid dealt round-robin) and, after
+ *                                      an in-kernel check that all workgroups of a problem really share an XCD, exchanges the
+ *                                      duals through that XCD's L2 (n = 256: 4.5 -> 2.4 us per iteration; same bits); else, and
+ *                                      with 0, the agent-scope exchange; 2 (tests): the check on the 2-D grid, which must fail
  *   sinkhorn_coop_max_wg      0        > 0: workgroups the multi-CU solver may assume co-resident (a caller that runs in a
  *                                      partition or under a CU mask); 0: queried from the device (CU count x occupancy, 3/4)
  *   smooth_stream             1        0: KernelSmoothing on the per-axis global stencils (any radius) instead of the

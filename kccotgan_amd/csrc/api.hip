@@ -31,6 +31,7 @@ static const OptDesc g_desc[OPT_COUNT] = {
     {"sinkhorn_fused_max_n", 64, 1, 128},
     {"sinkhorn_lanes_per_line", 0, 0, 16},
     {"sinkhorn_coop", 1, 0, 1},
+    {"sinkhorn_coop_xcd", 1, 0, 2},
     {"sinkhorn_coop_max_wg", 0, 0, 1 << 20},
     {"smooth_stream", 1, 0, 1},
     {"smooth_generic", 0, 0, 1},

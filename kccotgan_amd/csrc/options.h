@@ -16,6 +16,7 @@ enum Option {
     OPT_SK_FUSED_MAX_N,          // "sinkhorn_fused_max_n"
     OPT_SK_LPR,                  // "sinkhorn_lanes_per_line"
     OPT_SK_COOP,                 // "sinkhorn_coop"
+    OPT_SK_COOP_XCD,             // "sinkhorn_coop_xcd"
     OPT_SK_COOP_MAX_WG,          // "sinkhorn_coop_max_wg"
     OPT_SMOOTH_STREAM,           // "smooth_stream"
     OPT_SMOOTH_GENERIC,          // "smooth_generic"

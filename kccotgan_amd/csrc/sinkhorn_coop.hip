@@ -28,10 +28,13 @@ constexpr float SC_LOG2E = 1.4426950408889634f;
 constexpr float SC_LN2 = 0.6931471805599453f;
 
 struct CoopCtrl {            // per launch, zeroed in front of it
-    unsigned bar[32];        // arrival counters, one per problem
+    unsigned bar[32];        // arrival counters, one per problem (ll_same_xcd)
     int abort_flag;
-    int pad[31];
+    unsigned xcc_ref[8];     // XCC_ID + 1 of workgroup 0 of the problem, 0 = not published yet
+    unsigned mismatch[8];    // != 0: some workgroup of the problem sits on another XCD
+    int pad[15];
 };
+static_assert(sizeof(CoopCtrl) == 256, "the exchange words behind it are 8-byte aligned and the area is zeroed in 8-byte words");
 
 // one line's dual update: lane holds entries idx = lane + 64 e of its line (c) and of the other side's duals (o)
 template <int EPT, bool ROW>
@@ -74,8 +77,55 @@ __device__ __forceinline__ float coop_update(const float (&c)[EPT], const float 
 typedef unsigned long long ll_word;
 constexpr unsigned LL_FINAL_TAG = 0x7FFFFFFFu;
 
-__device__ __forceinline__ void ll_store(ll_word* p, float v, unsigned tag) {
-    __hip_atomic_store(p, ((ll_word)tag << 32) | (ll_word)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// local != 0 (one problem per XCD, ll_block): the word is stored with workgroup scope (sc0: it stays in the L2 of the
+// writer's XCD, which every reader of the problem shares; their sc1 loads bypass only their own L1).  Otherwise agent scope
+// (sc1: written through to memory, where a reader on any XCD finds it).
+__device__ __forceinline__ void ll_store(ll_word* p, float v, unsigned tag, int local) {
+    const ll_word w = ((ll_word)tag << 32) | (ll_word)__float_as_uint(v);
+    if (local) __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One problem per XCD is how the launch is LAID OUT; whether the hardware dealt the workgroups that way is checked here, once
+// per launch, with agent-scope traffic only (three round trips, ~5 us): workgroup 0 of the problem publishes its XCC_ID, every
+// workgroup compares its own, flags a mismatch, arrives at the problem's counter and waits for all nwg arrivals.  true = every
+// workgroup of problem p runs on one XCD and the L2-served exchange (ll_store with local != 0) may be used; false = agent scope
+// as before (a partitioned device, a CU mask, another dispatch order: slower, never wrong).  A workgroup that gives up
+// raises the abort flag like any other poll.  One wave per workgroup runs it; the result goes through LDS.
+__device__ __forceinline__ bool ll_same_xcd(CoopCtrl* c, int p, int wg, int nwg) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 0xFu) + 1u;
+    if (wg == 0) __hip_atomic_store(&c->xcc_ref[p], xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0, ref;
+    while ((ref = __hip_atomic_load(&c->xcc_ref[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+        if ((++spins & 127u) == 0 && (spins > SC_SPIN_LIMIT || __hip_atomic_load(&c->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(&c->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (ref != xcc) __hip_atomic_store(&c->mismatch[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the mismatch store of this workgroup is ordered in front of its arrival (release), the arrivals in front of the read
+    __hip_atomic_fetch_add(&c->bar[p], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    spins = 0;
+    while (__hip_atomic_load(&c->bar[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nwg) {
+        if ((++spins & 127u) == 0 && (spins > SC_SPIN_LIMIT || __hip_atomic_load(&c->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(&c->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return __hip_atomic_load(&c->mismatch[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+}
+
+// Block -> (problem, workgroup of the problem).  xcd_map: a 1-D grid of 8 * nwg blocks, block id -> problem id % 8,
+// workgroup id / 8 (workgroups are dealt to the 8 XCDs round-robin, so problem p lives on XCD p; ids whose residue is not a
+// problem leave at once); otherwise the 2-D grid (nwg, nprob).
+__device__ __forceinline__ bool ll_block(int xcd_map, int nprob, int& p, int& wg) {
+    if (xcd_map == 1) { p = blockIdx.x & 7; wg = blockIdx.x >> 3; return p < nprob; }
+    p = blockIdx.y; wg = blockIdx.x;
+    return true;
 }
 
 // Gather of x[0..n) with tag `tag` into sh[0..n): wave c < ceil(n/256) polls words 256c .. 256c+255 (four per lane).
@@ -126,6 +176,7 @@ struct SinkLLArgs {
     ll_word* xcost;   // [nprob][SC_MAXWG]
     int nwg, nprob;
     int fault;        // libkccot_diag.so only (KCCOT_SK_FAULT_INJECT=1): the last workgroup of problem 0 never takes part
+    int xcd_map;      // ll_block
 };
 
 template <int EPT>
@@ -134,7 +185,8 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
     __shared__ float shv[SC_MAXWG * SC_LINES];
     __shared__ float red[SC_MAXWG];
     __shared__ int bflag;
-    const int p = blockIdx.y, wg = blockIdx.x;
+    int p, wg;
+    if (!ll_block(a.xcd_map, a.nprob, p, wg)) return;
     if (a.fault && p == 0 && wg == a.nwg - 1) return;      // stands in for a workgroup that is not resident
     const int n = a.n, nwg = a.nwg;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -156,8 +208,11 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
         ccol[e] = C[(int64_t)clampi(e) * n + lsafe];
         ov[e] = 0.f; ou[e] = 0.f;                                  // gan_utils.py:147: u = v = 0
     }
-    if (t == 0) bflag = 0;
+    // (one problem per XCD by layout: verified here, once; `local` selects the L2-served exchange)
+    __shared__ int s_local;
+    if (t == 0) { bflag = 0; s_local = a.xcd_map ? (ll_same_xcd(a.ctrl, p, wg, a.nwg) ? 1 : 0) : 0; }
     __syncthreads();
+    const int local = s_local;
     float ui = 0.f, vj = 0.f;
     int nits = 0;
     bool ok = true;
@@ -166,7 +221,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
         const float un = coop_update<EPT, true>(crow, ov, n, lane, ui, eps, inv_eps, log_w);
         ui = un;
         if (lane == 0 && live) {
-            ll_store(xu + line, un, tagu);
+            ll_store(xu + line, un, tagu, local);
             if (a.u_hist) a.u_hist[((int64_t)p * a.L + it) * n + line] = un;
         }
         if (w < nchunk && !ll_gather(xu, tagu, shu, lane, w, n, &a.ctrl->abort_flag) && lane == 0) bflag = 1;
@@ -182,7 +237,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
         const float vn = coop_update<EPT, false>(ccol, ou, n, lane, vj, eps, inv_eps, log_w);
         vj = vn;
         if (lane == 0 && live) {
-            ll_store(xv + line, vn, tagv);
+            ll_store(xv + line, vn, tagv, local);
             if (a.v_hist) a.v_hist[((int64_t)p * a.L + it) * n + line] = vn;
         }
         if (w < nchunk && !ll_gather(xv, tagv, shv, lane, w, n, &a.ctrl->abort_flag) && lane == 0) bflag = 1;
@@ -217,7 +272,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < SC_LINES; ++k) s += red[k];
-        if (ok) ll_store(a.xcost + p * SC_MAXWG + wg, s, LL_FINAL_TAG);   // a workgroup that gave up never publishes
+        if (ok) ll_store(a.xcost + p * SC_MAXWG + wg, s, LL_FINAL_TAG, local);   // a workgroup that gave up never publishes
     }
     if (wg != 0 || w != 0) return;
     // workgroup 0, wave 0: the per-workgroup parts in workgroup order
@@ -263,6 +318,7 @@ struct SinkLLBwdArgs {
     ll_word* xgu;
     ll_word* xgv;
     int nwg, nprob;
+    int xcd_map;      // ll_block
 };
 
 template <int EPT>
@@ -270,7 +326,8 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
     __shared__ float shu[SC_MAXWG * SC_LINES];
     __shared__ float shv[SC_MAXWG * SC_LINES];
     __shared__ int bflag;
-    const int p = blockIdx.y, wg = blockIdx.x;
+    int p, wg;
+    if (!ll_block(a.xcd_map, a.nprob, p, wg)) return;
     const int n = a.n;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int line = wg * SC_LINES + w;
@@ -303,8 +360,11 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
         ccol[e] = C[(int64_t)clampi(e) * n + lsafe];
         drow[e] = 0.f; dcol[e] = 0.f;
     }
-    if (t == 0) bflag = 0;
+    // (one problem per XCD by layout: verified here, once; `local` selects the L2-served exchange)
+    __shared__ int s_local;
+    if (t == 0) { bflag = 0; s_local = a.xcd_map ? (ll_same_xcd(a.ctrl, p, wg, a.nwg) ? 1 : 0) : 0; }
     __syncthreads();
+    const int local = s_local;
     auto hist = [&](const float* h, int it, int i) { return it >= 1 ? h[(int64_t)(it - 1) * n + i] : 0.f; };
     // final-cost term: dC = g pi (1 - C/eps); gu = g sum_j pi C / eps; gv likewise
     float gu_line, gv_line;
@@ -322,7 +382,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
         }
         gu_line = g * wave_sum_fast(su) * inv_eps;
         gv_line = g * wave_sum_fast(sv) * inv_eps;
-        if (lane == 0 && live) ll_store(xgv + line, gv_line, 1u);
+        if (lane == 0 && live) ll_store(xgv + line, gv_line, 1u, local);
     }
     unsigned tag = 1u;       // the tag of the gv values the next (A) pass reads
     for (int it = nits; it >= 1; --it) {
@@ -349,7 +409,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
             }
             s = wave_sum_fast(s);
             gu_line = (it == nits ? gu_line : 0.f) - s;
-            if (lane == 0 && live) ll_store(xgu + line, gu_line, tag + 1u);
+            if (lane == 0 && live) ll_store(xgu + line, gu_line, tag + 1u, local);
         }
         // (B) column pass with P_t: gv_j = -sum_i P_ij gu_i ; dC_ij += P_ij gu_i (kept in column layout)
         if (w < nchunk && !ll_gather(xgu, tag + 1u, shu, lane, w, n, &a.ctrl->abort_flag) && lane == 0) bflag = 1;
@@ -367,7 +427,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
             }
             r = wave_sum_fast(r);
             gv_line = -r;
-            if (lane == 0 && live) ll_store(xgv + line, gv_line, tag + 2u);
+            if (lane == 0 && live) ll_store(xgv + line, gv_line, tag + 2u, local);
         }
         tag += 2u;
     }
@@ -449,6 +509,15 @@ static int ll_zero_area(void* p, size_t bytes, hipStream_t st) {      // bytes %
     return launch_status("ll_zero");
 }
 
+// option "sinkhorn_coop_xcd" = 1 (default): one problem per XCD (ll_block) -- when there are at most 8 problems and an
+// XCD's share of the co-residency capacity holds a whole problem
+// (value 2, tests: the 2-D grid launched as if it were laid out per XCD -- the in-kernel check must find the mismatch and
+// fall back to the agent-scope exchange)
+static int ll_xcd_map(int nprob, int nwg) {
+    const int o = opt(OPT_SK_COOP_XCD);
+    return (o && nprob <= 8 && nwg <= coop_capacity() / 8) ? o : 0;
+}
+
 // flag-in-data kernels: ctrl | xu [nprob][n] words | xv | xcost [nprob][SC_MAXWG] words, zeroed as one block
 struct LLCarve { CoopCtrl* ctrl; ll_word* x0; ll_word* x1; ll_word* xc; size_t zero_bytes; float* second; };
 static LLCarve ll_carve(void* ws, int nprob, int n) {
@@ -470,8 +539,8 @@ int launch_sinkhorn_fwd_coop(const float* C, int nprob, int n, float eps, int L,
     if (int zrc = ll_zero_area(lv.ctrl, lv.zero_bytes, st)) return zrc;
     const int nwg = (n + SC_LINES - 1) / SC_LINES;
     SinkLLArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
-                 lv.ctrl, lv.x0, lv.x1, lv.xc, nwg, nprob, fault_injected()};
-    const dim3 grid(nwg, nprob);
+                 lv.ctrl, lv.x0, lv.x1, lv.xc, nwg, nprob, fault_injected(), ll_xcd_map(nprob, nwg)};
+    const dim3 grid = a.xcd_map == 1 ? dim3(8 * nwg) : dim3(nwg, nprob);
     const int ept = (n + 63) / 64;
 #define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_fwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)
     if (ept <= 4) KCCOT_LL(4); else if (ept <= 8) KCCOT_LL(8); else KCCOT_LL(16);
@@ -486,8 +555,8 @@ int launch_sinkhorn_bwd_coop(const float* C, const float* u_hist, const float* v
     if (int zrc = ll_zero_area(lv.ctrl, lv.zero_bytes, st)) return zrc;
     const int nwg = (n + SC_LINES - 1) / SC_LINES;
     SinkLLBwdArgs a{C, u_hist, v_hist, nits, gcost, dC, lv.second, n, L, eps, (float)(1.0 / (double)eps), lv.ctrl, lv.x0, lv.x1,
-                    nwg, nprob};
-    const dim3 grid(nwg, nprob);
+                    nwg, nprob, ll_xcd_map(nprob, nwg)};
+    const dim3 grid = a.xcd_map == 1 ? dim3(8 * nwg) : dim3(nwg, nprob);
     const int ept = (n + 63) / 64;
 #define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_bwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)
     if (ept <= 4) KCCOT_LL(4); else if (ept <= 8) KCCOT_LL(8); else KCCOT_LL(16);

@@ -536,6 +536,30 @@ def test_multi_cu_sinkhorn_replays_as_a_graph(G, L, n):
         assert gn.tolist() == n0.tolist() and torch.equal(gl, l0) and torch.equal(gd, d0), "back-to-back replays"
 
 
+@pytest.mark.parametrize("n", [130, 200, 256, 384])
+def test_multi_cu_sinkhorn_exchange_through_the_xcd_l2_is_bit_identical(G, L, n):
+    """Option "sinkhorn_coop_xcd": 1 = one problem per XCD by layout, verified in the kernel, duals exchanged through the L2
+    the problem's workgroups share (the default); 0 = the agent-scope exchange on the 2-D grid; 2 = the check on the 2-D
+    grid, where it must FAIL and fall back (a wrongly passing check would leave the workgroups blind to each other: abort,
+    NaN).  Same arithmetic on the same values: costs, iteration counts, dual histories and dC agree bit for bit."""
+    from kccotgan_amd.dist import HipOps as H
+    gen = torch.Generator(device=DEV).manual_seed(1000 + n)
+    C3 = torch.rand((3, n, n), device=DEV, generator=gen) * 25
+    g3 = torch.tensor([2.0, -1.0, -1.0], device=DEV)
+    out = {}
+    with L.options(sinkhorn_shortcut=0):
+        for mode in (1, 0, 2):
+            with L.options(sinkhorn_coop_xcd=mode):
+                cost, saved = H.sinkhorn3_fwd(C3, 1.0, 100)
+                dC = H.sinkhorn3_bwd(saved, g3)
+                torch.cuda.synchronize()
+                out[mode] = (cost.clone(), saved[1].clone(), saved[2].clone(), saved[3].clone(), dC.clone())
+    assert out[1][3][:3].tolist() == [100, 100, 100] and bool(torch.isfinite(out[1][4]).all())
+    for mode in (0, 2):
+        for a_, b_ in zip(out[1], out[mode]):
+            assert torch.equal(a_, b_), (n, mode)
+
+
 def test_graphed_loss_step_at_a_large_batch(G, L):
     """GraphedLossStep at B = 256 (256-row Gram tiles, multi-CU Sinkhorn, one-launch video gradient): replays equal the
     eager step bit for bit, repeatedly, and see new inputs."""

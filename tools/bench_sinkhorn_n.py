@@ -9,7 +9,9 @@ import numpy as np, torch
 from kccotgan_amd._lib import lib, ptr
 
 from kccotgan_amd import _lib
-VARIANTS = {"multi-CU (flag-in-data)": dict(sinkhorn_coop=1), "one workgroup (streaming)": dict(sinkhorn_coop=0)}
+VARIANTS = {"multi-CU, problem per XCD": dict(sinkhorn_coop=1, sinkhorn_coop_xcd=1), "multi-CU, 2-D grid": dict(sinkhorn_coop=1, sinkhorn_coop_xcd=0),
+            "multi-CU, 2-D grid + failing XCD check": dict(sinkhorn_coop=1, sinkhorn_coop_xcd=2),
+            "one workgroup (streaming)": dict(sinkhorn_coop=0)}
 
 
 def run(n, L=100):
@@ -38,7 +40,8 @@ def run(n, L=100):
         print("n=%d %-26s fwd %8.1f us (%.2f us/iter)  bwd %8.1f us  nits %s cost %s" % (
             n, name, tf, tf / L, tb, nits.tolist()[:3], [round(c, 5) for c in cost.tolist()]), flush=True)
     names = list(VARIANTS)
-    ref, r = res[names[0]], res[names[1]]
+    print("   the two multi-CU block maps: bit-identical %s" % all(bool((a == b).all()) for k in (1, 2) for a, b in zip(res[names[0]], res[names[k]])), flush=True)
+    ref, r = res[names[0]], res[names[3]]
     print("   streaming vs multi-CU: cost rel %.2e  nits equal %s  u_hist max|d| %.2e  dC max|d|/max %.2e  finite %s" % (
         float(np.abs(r[0] - ref[0]).max() / np.abs(ref[0]).max()), bool((r[1] == ref[1]).all()),
         float(np.abs(r[2] - ref[2]).max()), float(np.abs(r[3] - ref[3]).max() / np.abs(ref[3]).max()),
