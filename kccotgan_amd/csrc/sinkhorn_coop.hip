@@ -456,25 +456,30 @@ static bool coop_enabled() { return opt(OPT_SK_COOP) != 0; }   // option "sinkho
 // collective of the data-parallel trainer, another stream) does not turn a legal launch into a bounded-poll abort.
 // A partitioned / CU-masked / smaller device simply reports fewer CUs and larger batches take the streaming solver.
 // Option "sinkhorn_coop_max_wg" = n > 0 overrides the result (a caller that knows its partition; tests force the fallback).
-static int coop_capacity() {
-    static int cached[64];
+// `ept` = 0: the bound for any n (the fattest instantiation); 4 / 8 / 16: for the instantiation that serves that n.
+static int coop_capacity(int ept = 0) {
+    static int cached[64][4];
     static bool have[64];
     if (const int forced = opt(OPT_SK_COOP_MAX_WG)) return forced;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     if (!have[dev]) {
-        int cus = 0, per_cu = 0, m = 1 << 30;
+        int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-#define KCCOT_OCC(K)                                                                                              \
+        int occ[3] = {1 << 30, 1 << 30, 1 << 30};
+#define KCCOT_OCC(K, I)                                                                                           \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K, SC_THREADS, 0) != hipSuccess) per_cu = 0;        \
-        m = per_cu < m ? per_cu : m;
-        KCCOT_OCC(sinkhorn_fwd_ll<4>) KCCOT_OCC(sinkhorn_fwd_ll<8>) KCCOT_OCC(sinkhorn_fwd_ll<16>)
-        KCCOT_OCC(sinkhorn_bwd_ll<4>) KCCOT_OCC(sinkhorn_bwd_ll<8>) KCCOT_OCC(sinkhorn_bwd_ll<16>)
+        occ[I] = per_cu < occ[I] ? per_cu : occ[I];
+        KCCOT_OCC(sinkhorn_fwd_ll<4>, 0) KCCOT_OCC(sinkhorn_fwd_ll<8>, 1) KCCOT_OCC(sinkhorn_fwd_ll<16>, 2)
+        KCCOT_OCC(sinkhorn_bwd_ll<4>, 0) KCCOT_OCC(sinkhorn_bwd_ll<8>, 1) KCCOT_OCC(sinkhorn_bwd_ll<16>, 2)
 #undef KCCOT_OCC
-        cached[dev] = (int)((long long)cus * m * 3 / 4);
+        int m = occ[0] < occ[1] ? occ[0] : occ[1];
+        m = occ[2] < m ? occ[2] : m;
+        cached[dev][0] = (int)((long long)cus * m * 3 / 4);
+        for (int i = 0; i < 3; ++i) cached[dev][1 + i] = (int)((long long)cus * occ[i] * 3 / 4);
         have[dev] = true;
     }
-    return cached[dev];
+    return cached[dev][ept == 4 ? 1 : (ept == 8 ? 2 : (ept == 16 ? 3 : 0))];
 }
 
 bool sinkhorn_coop_eligible(int nprob, int n) {
@@ -513,9 +518,9 @@ static int ll_zero_area(void* p, size_t bytes, hipStream_t st) {      // bytes %
 // XCD's share of the co-residency capacity holds a whole problem
 // (value 2, tests: the 2-D grid launched as if it were laid out per XCD -- the in-kernel check must find the mismatch and
 // fall back to the agent-scope exchange)
-static int ll_xcd_map(int nprob, int nwg) {
+static int ll_xcd_map(int nprob, int nwg, int ept) {
     const int o = opt(OPT_SK_COOP_XCD);
-    return (o && nprob <= 8 && nwg <= coop_capacity() / 8) ? o : 0;
+    return (o && nprob <= 8 && nwg <= coop_capacity(ept) / 8) ? o : 0;
 }
 
 // flag-in-data kernels: ctrl | xu [nprob][n] words | xv | xcost [nprob][SC_MAXWG] words, zeroed as one block
@@ -538,10 +543,10 @@ int launch_sinkhorn_fwd_coop(const float* C, int nprob, int n, float eps, int L,
     if (lv.zero_bytes > sinkhorn_gen_workspace_bytes(nprob, n) / 2) return fail(KCCOT_EWORKSPACE, "sinkhorn_fwd(coop): exchange area");
     if (int zrc = ll_zero_area(lv.ctrl, lv.zero_bytes, st)) return zrc;
     const int nwg = (n + SC_LINES - 1) / SC_LINES;
-    SinkLLArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
-                 lv.ctrl, lv.x0, lv.x1, lv.xc, nwg, nprob, fault_injected(), ll_xcd_map(nprob, nwg)};
-    const dim3 grid = a.xcd_map == 1 ? dim3(8 * nwg) : dim3(nwg, nprob);
     const int ept = (n + 63) / 64;
+    SinkLLArgs a{C, n, L, Lmin, stop_mode, eps, (float)(1.0 / (double)eps), thresh, u_hist, v_hist, cost_out, nits_out, pi_out,
+                 lv.ctrl, lv.x0, lv.x1, lv.xc, nwg, nprob, fault_injected(), ll_xcd_map(nprob, nwg, ept <= 4 ? 4 : (ept <= 8 ? 8 : 16))};
+    const dim3 grid = a.xcd_map == 1 ? dim3(8 * nwg) : dim3(nwg, nprob);
 #define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_fwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)
     if (ept <= 4) KCCOT_LL(4); else if (ept <= 8) KCCOT_LL(8); else KCCOT_LL(16);
 #undef KCCOT_LL
@@ -554,10 +559,10 @@ int launch_sinkhorn_bwd_coop(const float* C, const float* u_hist, const float* v
     if (lv.zero_bytes > sinkhorn_gen_workspace_bytes(nprob, n) / 2) return fail(KCCOT_EWORKSPACE, "sinkhorn_bwd(coop): exchange area");
     if (int zrc = ll_zero_area(lv.ctrl, lv.zero_bytes, st)) return zrc;
     const int nwg = (n + SC_LINES - 1) / SC_LINES;
-    SinkLLBwdArgs a{C, u_hist, v_hist, nits, gcost, dC, lv.second, n, L, eps, (float)(1.0 / (double)eps), lv.ctrl, lv.x0, lv.x1,
-                    nwg, nprob, ll_xcd_map(nprob, nwg)};
-    const dim3 grid = a.xcd_map == 1 ? dim3(8 * nwg) : dim3(nwg, nprob);
     const int ept = (n + 63) / 64;
+    SinkLLBwdArgs a{C, u_hist, v_hist, nits, gcost, dC, lv.second, n, L, eps, (float)(1.0 / (double)eps), lv.ctrl, lv.x0, lv.x1,
+                    nwg, nprob, ll_xcd_map(nprob, nwg, ept <= 4 ? 4 : (ept <= 8 ? 8 : 16))};
+    const dim3 grid = a.xcd_map == 1 ? dim3(8 * nwg) : dim3(nwg, nprob);
 #define KCCOT_LL(E) hipLaunchKernelGGL(sinkhorn_bwd_ll<E>, grid, dim3(SC_THREADS), 0, st, a)
     if (ept <= 4) KCCOT_LL(4); else if (ept <= 8) KCCOT_LL(8); else KCCOT_LL(16);
 #undef KCCOT_LL

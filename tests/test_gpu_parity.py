@@ -536,7 +536,7 @@ def test_multi_cu_sinkhorn_replays_as_a_graph(G, L, n):
         assert gn.tolist() == n0.tolist() and torch.equal(gl, l0) and torch.equal(gd, d0), "back-to-back replays"
 
 
-@pytest.mark.parametrize("n", [130, 200, 256, 384])
+@pytest.mark.parametrize("n", [130, 200, 256, 384, 512, 640])
 def test_multi_cu_sinkhorn_exchange_through_the_xcd_l2_is_bit_identical(G, L, n):
     """Option "sinkhorn_coop_xcd": 1 = one problem per XCD by layout, verified in the kernel, duals exchanged through the L2
     the problem's workgroups share (the default); 0 = the agent-scope exchange on the 2-D grid; 2 = the check on the 2-D
