@@ -198,7 +198,7 @@ def live_pmc_traffic(kernel_prefix="gram128_partial", timeout_s=120):
 def time_sinkhorn(C3, L=100, reps=50):
     """The three-problem solve and its reverse sweep alone (every iteration executed: main sets the option
     "sinkhorn_shortcut" = 0): us per launch and per dependent half-step."""
-    from kccotgan_amd._lib import lib, ptr, stream_of, check
+    from kccotgan_amd._lib import lib, ptr, stream_of, check, workspace
     n = C3.shape[1]
     dev = C3.device
     uh, vh = torch.empty(3, L, n, device=dev), torch.empty(3, L, n, device=dev)
@@ -224,7 +224,24 @@ def time_sinkhorn(C3, L=100, reps=50):
         fu_us = time_launches(fu, reps, 5)
         fused = {"fused_fwd_bwd_us": fu_us, "fused_us_per_half_step": fu_us / (4 * its),
                  "fused_over_floor": fu_us / (4 * its) / floor_us, "two_launch_fwd_plus_bwd_us": f_us + b_us}
-    return {"n": n, "iterations": its, "fwd_us": f_us, "bwd_us": b_us, **fused,
+    # the multi-CU solver of the larger configs (n = 256 = configs[3]): one problem per XCD, duals through that XCD's L2
+    multi = {}
+    try:
+        from kccotgan_amd import _lib as _kl
+        nm = 256
+        Cm = torch.rand((3, nm, nm), device=C3.device) * 30
+        uhm, vhm = torch.empty(3, L, nm, device=C3.device), torch.empty(3, L, nm, device=C3.device)
+        cm, nim = torch.empty(3, device=C3.device), torch.zeros(6, dtype=torch.int32, device=C3.device)
+        wsm, wsbm = workspace(lib.kccot_sinkhorn_workspace_bytes(3, nm), Cm)
+        fm = lambda: check(lib.kccot_sinkhorn_fwd_f32(ptr(Cm), 3, nm, 1.0, L, 100, 1e-2, 0, ptr(uhm), ptr(vhm), ptr(cm), ptr(nim),
+                                                      None, wsm, wsbm, st), "sk_fwd_n256")
+        for mode, key in ((1, "xcd_l2_exchange"), (0, "agent_scope_exchange")):
+            with _kl.options(sinkhorn_coop_xcd=mode):
+                us = time_launches(fm, 20, 3)
+            multi["n256_fwd_us_per_iteration_" + key] = us / max(int(nim[:3].max()), 1)
+    except Exception as e:
+        multi = {"n256_error": repr(e)}
+    return {"n": n, "iterations": its, "fwd_us": f_us, "bwd_us": b_us, **fused, "multi_cu": multi,
             "fwd_us_per_half_step": f_us / (2 * its), "bwd_us_per_half_step": b_us / (2 * its),
             "fwd_cycles_per_half_step_at_2.4GHz": f_us / (2 * its) * PEAK_CLOCK_GHZ * 1e3,
             "exp_issue_floor_cycles": 256, "exp_issue_floor_us_per_half_step": floor_us,
