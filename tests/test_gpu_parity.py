@@ -560,6 +560,36 @@ def test_multi_cu_sinkhorn_exchange_through_the_xcd_l2_is_bit_identical(G, L, n)
             assert torch.equal(a_, b_), (n, mode)
 
 
+@pytest.mark.parametrize("nprob", [1, 8, 9])
+def test_multi_cu_sinkhorn_problem_counts_around_the_xcd_layout(L, nprob):
+    """kccot_sinkhorn_fwd_f32 / bwd at n = 160 with 1, 8 (one problem per XCD, all eight used) and 9 problems (more than XCDs:
+    the 2-D grid with the agent-scope exchange): every problem against the same problem solved alone with the layout off."""
+    from kccotgan_amd._lib import lib, ptr, check, workspace
+    n, Lit = 160, 100
+    gen = torch.Generator(device=DEV).manual_seed(50 + nprob)
+    C = (torch.rand((nprob, n, n), device=DEV, generator=gen) * 20).contiguous()
+    gc = torch.randn((nprob,), device=DEV, generator=gen)
+
+    def solve(Cs, g, xcd):
+        k = Cs.shape[0]
+        uh, vh = torch.empty(k, Lit, n, device=DEV), torch.empty(k, Lit, n, device=DEV)
+        cost, nits = torch.empty(k, device=DEV), torch.zeros(2 * k, dtype=torch.int32, device=DEV)
+        dC = torch.empty_like(Cs)
+        ws, wsb = workspace(lib.kccot_sinkhorn_workspace_bytes(k, n), Cs)
+        with L.options(sinkhorn_shortcut=0, sinkhorn_coop_xcd=xcd):
+            check(lib.kccot_sinkhorn_fwd_f32(ptr(Cs), k, n, 1.0, Lit, 100, 1e-2, 0, ptr(uh), ptr(vh), ptr(cost), ptr(nits), None, ws, wsb,
+                                             None), "fwd")
+            check(lib.kccot_sinkhorn_bwd_f32(ptr(Cs), ptr(uh), ptr(vh), ptr(nits), k, n, 1.0, Lit, ptr(g), ptr(dC), ws, wsb, None), "bwd")
+        torch.cuda.synchronize()
+        return cost, nits[:k], dC
+
+    cost, nits, dC = solve(C, gc, 1)
+    assert nits.tolist() == [100] * nprob and bool(torch.isfinite(dC).all())
+    for p in range(nprob):
+        c1, n1, d1 = solve(C[p:p + 1].contiguous(), gc[p:p + 1].contiguous(), 0)
+        assert torch.equal(c1[0], cost[p]) and int(n1[0]) == int(nits[p]) and torch.equal(d1[0], dC[p]), p
+
+
 def test_graphed_loss_step_at_a_large_batch(G, L):
     """GraphedLossStep at B = 256 (256-row Gram tiles, multi-CU Sinkhorn, one-launch video gradient): replays equal the
     eager step bit for bit, repeatedly, and see new inputs."""
