@@ -316,6 +316,30 @@ def train_steps_child(timeout_s=150, fallback_timeout_s=240):
             "pM": r["pm"], "loss": r["loss"], "child_wall_s": time.perf_counter() - t0}
 
 
+def box_probe(dev):
+    """What this box's memory system delivers on multi-GB buffers, independent of any kccot kernel: a 4 GiB device-to-device
+    copy (read + write).  Context for the `configs` block: some boxes of the pool run every multi-GB workload 3-4x slower than
+    others (configs[4]: 82 ms against 27.7 ms with the same library) while everything up to a few hundred MB is unaffected."""
+    try:
+        n = 1 << 30
+        a = torch.empty(n, dtype=torch.float32, device=dev).fill_(1.0)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        del a, b
+        torch.cuda.empty_cache()
+        return {"d2d_copy_4GiB_ms": ms, "read_plus_write_GBps": 2 * 4 * n / ms / 1e6}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def config_inputs(B, H, T, W, C, dev, seed=0):
     g = torch.Generator(device=dev).manual_seed(seed)
     real = torch.rand((B, H, T, W, C), device=dev, generator=g)
@@ -714,6 +738,7 @@ def main():
             sys.stderr.write("bench: configs block failed on rank %d: %r\n" % (rank, e))
         if rank == 0 and cfgs:
             out["configs"] = cfgs
+            out["box_probe"] = box_probe(dev)
         if rank == 0 and world == 1:
             try:
                 out["kernel_smoothing"] = time_smoothing(dev)
