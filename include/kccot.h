@@ -86,8 +86,8 @@ const char* kccot_last_error(void);
  *                                      with 0, the agent-scope exchange; 2 (tests): the check on the 2-D grid, which must fail
  *   sinkhorn_coop_max_wg      0        > 0: workgroups the multi-CU solver may assume co-resident (a caller that runs in a
  *                                      partition or under a CU mask); 0: queried from the device (CU count x occupancy, 3/4)
- *                                      (256 on a whole MI355X also lets n = 512 use the per-XCD layout of sinkhorn_coop_xcd:
- *                                      32 workgroups = every CU of an XCD)
+ *                                      (384 on a whole MI355X also lets n = 512 use the per-XCD layout of sinkhorn_coop_xcd:
+ *                                      32 workgroups = every CU of an XCD; by default only n <= 256 = half an XCD)
  *   smooth_stream             1        0: KernelSmoothing on the per-axis global stencils (any radius) instead of the
  *                                      streaming kernels (radius 3 / 4)
  *   smooth_generic            0        1: the any-length / any-alignment streaming kernels even where the register-line ones apply

@@ -514,13 +514,16 @@ static int ll_zero_area(void* p, size_t bytes, hipStream_t st) {      // bytes %
     return launch_status("ll_zero");
 }
 
-// option "sinkhorn_coop_xcd" = 1 (default): one problem per XCD (ll_block) -- when there are at most 8 problems and an
+// option "sinkhorn_coop_xcd" = 1 (default): one problem per XCD (ll_block) -- when there are at most 8 problems and HALF an
 // XCD's share of the co-residency capacity holds a whole problem
 // (value 2, tests: the 2-D grid launched as if it were laid out per XCD -- the in-kernel check must find the mismatch and
 // fall back to the agent-scope exchange)
 static int ll_xcd_map(int nprob, int nwg, int ept) {
     const int o = opt(OPT_SK_COOP_XCD);
-    return (o && nprob <= 8 && nwg <= coop_capacity(ept) / 8) ? o : 0;
+    // half of an XCD's share of the co-residency capacity (16 of 32 CUs on an MI355X: n <= 256): two processes that share the
+    // card (or two streams of one) can then both be resident on the XCD -- with partial residency of both, each would poll
+    // for workgroups that cannot start until the other finishes, and both would give up
+    return (o && nprob <= 8 && nwg <= coop_capacity(ept) / 12) ? o : 0;
 }
 
 // flag-in-data kernels: ctrl | xu [nprob][n] words | xv | xcost [nprob][SC_MAXWG] words, zeroed as one block
