@@ -313,19 +313,18 @@ __device__ __forceinline__ void sinkhorn_fwd_body(const SinkArgs& a) {
     }
     const float cost = block_sum(part, red);
     if (t == 0) {
-        a.cost_out[p] = cost;
+        // the last of the three workgroups to arrive combines the costs (gan_utils.py:225).  Placement-independent
+        // hand-off without fences (MI355X_MICROARCH.md, valid forms): the handed-off word is stored with agent scope
+        // (written through), the store drained (vmcnt(0)), then the relaxed ticket; the last arriver reads the costs with
+        // agent-scope loads.  (Until round 3: plain store + agent release fence + acquire fence in the last arriver -- an L2
+        // write-back and an L1 invalidate, ~1.7 us each, on the one thread the workgroup then waits for.)
+        __hip_atomic_store(a.cost_out + p, cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.nits_out[p] = nits;
         a.nits_out[gridDim.x + p] = computed;
         if (a.loss_out) {
-            // the last of the three workgroups to arrive combines the costs (gan_utils.py:225).
-            // Placement-independent hand-off (cdna_hip_programming.md G16, counter form): plain store ->
-            // agent-scope release -> relaxed ticket; the last arriver reads the costs with agent-scope
-            // (L1-bypassing) loads.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int tk = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tk == (int)gridDim.x - 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const float c0 = __hip_atomic_load(a.cost_out + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const float c1 = __hip_atomic_load(a.cost_out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const float c2 = __hip_atomic_load(a.cost_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -661,14 +660,13 @@ __global__ __launch_bounds__(LPR * SK_MAXN < SK_MAXT ? LPR * SK_MAXN : SK_MAXT) 
     }
     const float cost = block_sum(part, red);
     if (t == 0) {
-        a.cost_out[p] = cost;
+        // (fence-free hand-off as in sinkhorn_fwd_body: agent-scope store, drained, then the ticket)
+        __hip_atomic_store(a.cost_out + p, cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.nits_out[p] = nits;
         a.nits_out[gridDim.x + p] = computed;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int tk = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tk == (int)gridDim.x - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float c0 = __hip_atomic_load(a.cost_out + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float c1 = __hip_atomic_load(a.cost_out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float c2 = __hip_atomic_load(a.cost_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
