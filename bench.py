@@ -156,7 +156,7 @@ def live_pmc_traffic(kernel_prefix="gram128_partial", timeout_s=120):
     prescribes) over a child process that only launches that kernel; counters in KiB, FETCH_SIZE doubled (gfx950 counts a
     wide coalesced read at half its bytes).  Returns (bytes, note) or (None, reason): any failure -- no rocprofv3, a
     profiler already attached to this process, a timeout -- leaves the committed figure of profiles/hbm_traffic.json."""
-    import csv, glob, shutil, subprocess, tempfile
+    import csv, glob, shutil, signal, subprocess, tempfile
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
@@ -170,10 +170,21 @@ def live_pmc_traffic(kernel_prefix="gram128_partial", timeout_s=120):
             out_dir = os.path.join(tmp, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child"]
-            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
-            if r.returncode != 0:
-                tail = " | ".join(r.stdout.decode(errors="replace").strip().splitlines()[-3:])
-                return None, "rocprofv3 --pmc %s exited with %d: %s" % (counter, r.returncode, tail[-300:])
+            # own session: on a timeout the WHOLE group dies (rocprofv3 is a launcher -- killing only it would orphan the
+            # python child that owns the GPU, and that child would overlap every timing taken afterwards)
+            proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                stdout, _ = proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.communicate()
+                return None, "rocprofv3 --pmc %s timed out after %d s (process group killed)" % (counter, timeout_s)
+            if proc.returncode != 0:
+                tail = " | ".join(stdout.decode(errors="replace").strip().splitlines()[-3:])
+                return None, "rocprofv3 --pmc %s exited with %d: %s" % (counter, proc.returncode, tail[-300:])
             vals = []
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -182,8 +193,6 @@ def live_pmc_traffic(kernel_prefix="gram128_partial", timeout_s=120):
             if not vals:
                 return None, "no %s rows for %s" % (counter, kernel_prefix)
             per[counter] = (sum(vals) / len(vals), len(vals))
-    except subprocess.TimeoutExpired:
-        return None, "rocprofv3 pass timed out after %d s" % timeout_s
     except Exception as e:            # the bench line must not depend on the profiler
         return None, "counter pass failed: %r" % (e,)
     finally:

@@ -203,17 +203,24 @@ def require_gpu(t):
         raise KccotError("kccotgan_amd needs tensors on a ROCm device (got %s); there is no CPU path" % t.device)
 
 
-def ptr(t):
-    """Device address of a tensor (None -> NULL).  Refuses anything the kernels cannot read."""
+def ptr(t, dtypes=(torch.float32, torch.int32)):
+    """Device address of a tensor (None -> NULL).  Refuses anything the kernels cannot read: the ABI's `float*` / `int*`
+    parameters take fp32 / int32 tensors only -- a float64 tensor here would be reinterpreted, not converted."""
     if t is None:
         return None
     if not t.is_cuda:
         raise KccotError("kccotgan_amd needs tensors on a ROCm device (got %s); there is no CPU path" % t.device)
-    if t.dtype not in (torch.float32, torch.int32, torch.float64):      # float64: the Gram sums / row norms of the sharded path
-        raise TypeError("kccotgan_amd kernels are fp32 (got %s)" % t.dtype)
+    if t.dtype not in dtypes:
+        raise TypeError("kccotgan_amd kernel argument must be %s (got %s)" % (" / ".join(str(d) for d in dtypes), t.dtype))
     if not t.is_contiguous():
         raise ValueError("kccotgan_amd kernels need contiguous tensors")
     return t.data_ptr()
+
+
+def ptr_f64(t):
+    """Device address of a float64 tensor: ONLY for the `double*` parameters of the ABI (fp64 Gram sums and row norms of
+    the sharded path: kccot_row_norms_f64, kccot_pairwise_cost3_rows_gram*_f64/_from_sums_f32)."""
+    return ptr(t, (torch.float64,))
 
 
 def stream_of(t):

@@ -314,9 +314,14 @@ __device__ __forceinline__ void sinkhorn_fwd_body(const SinkArgs& a) {
     const float cost = block_sum(part, red);
     if (t == 0) {
         // the last of the three workgroups to arrive combines the costs (gan_utils.py:225).  Placement-independent
-        // hand-off without fences (MI355X_MICROARCH.md, valid forms): the handed-off word is stored with agent scope
-        // (written through), the store drained (vmcnt(0)), then the relaxed ticket; the last arriver reads the costs with
-        // agent-scope loads.  (Until round 3: plain store + agent release fence + acquire fence in the last arriver -- an L2
+        // hand-off without fences -- the FIRST ROW of MI355X_MICROARCH.md's table of measured hand-offs ("one lane of each
+        // storing workgroup ... an agent-scope atomic add; the workgroup whose add came last, told by the value its add
+        // returned, loads only after its add has returned; stores all sc1, loads all sc1, 4-byte"): the handed-off word is
+        // stored with agent scope (written through), the store drained (vmcnt(0)), then the relaxed ticket; the last arriver
+        // reads the costs with agent-scope loads.  This is gfx950 behaviour, not a guarantee of the HIP memory model (under
+        // which it is a race): the emitted cache-policy bits and the drain are pinned by
+        // tests/test_abi.py::test_isa_of_the_three_cost_hand_off_to_the_combining_workgroup, and this library builds for
+        // gfx950 only.  (Until round 3: plain store + agent release fence + acquire fence in the last arriver -- an L2
         // write-back and an L1 invalidate, ~1.7 us each, on the one thread the workgroup then waits for.)
         __hip_atomic_store(a.cost_out + p, cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.nits_out[p] = nits;

@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include "options.h"
 
 namespace kccot {
@@ -27,14 +28,17 @@ constexpr unsigned SC_SPIN_LIMIT = 1u << 20; // polls (an L2 round trip each) be
 constexpr float SC_LOG2E = 1.4426950408889634f;
 constexpr float SC_LN2 = 0.6931471805599453f;
 
-struct CoopCtrl {            // per launch, zeroed in front of it
+struct CoopCtrl {            // per launch, zeroed in front of it -- except `epoch`, which ll_zero INCREMENTS
     unsigned bar[32];        // arrival counters, one per problem (ll_same_xcd)
+    unsigned long long epoch;// launch counter of this workspace: the upper bits of every exchange tag (ll_tag_base)
     int abort_flag;
     unsigned xcc_ref[8];     // XCC_ID + 1 of workgroup 0 of the problem, 0 = not published yet
     unsigned mismatch[8];    // != 0: some workgroup of the problem sits on another XCD
-    int pad[15];
+    int pad[13];
 };
 static_assert(sizeof(CoopCtrl) == 256, "the exchange words behind it are 8-byte aligned and the area is zeroed in 8-byte words");
+static_assert(offsetof(CoopCtrl, epoch) == 128, "ll_zero skips (and bumps) 64-bit word 16 of the area");
+constexpr int LL_EPOCH_WORD = 16;
 
 // one line's dual update: lane holds entries idx = lane + 64 e of its line (c) and of the other side's duals (o)
 template <int EPT, bool ROW>
@@ -74,8 +78,22 @@ __device__ __forceinline__ float coop_update(const float (&c)[EPT], const float 
 // The stop test needs sum_i |u_i - u_i_prev| (gan_utils.py:157): every wave holds all of u (new and previous) across
 // its lanes after the gather, so each wave sums it for itself in the same fixed order -- identical decisions, no
 // exchange.
+//
+// Tags carry the LAUNCH in their upper bits (round 4): tag = (epoch & 0x7FF) << 20 | half-step, epoch = a counter that lives
+// in the exchange area and is incremented by the zeroing kernel in front of every launch -- also in front of every REPLAY of a
+// captured launch, which a host-side counter in the kernel arguments could not be (they are frozen at capture).  Half-step
+// numbers restart at 1 in every launch; without the epoch a word left over from the previous launch that escaped the zeroing
+// (round 3 saw exactly that with memset nodes in a graph) would carry a valid-looking tag with an OLD value and be consumed
+// silently.  With it such a word can only make a poll run to its bound: NaN + KCCOT_EABORTED, never a plausible number.
+// (2047 launches later the epoch bits repeat; the zeroing kernel remains the primary guarantee, the epoch the second.)
 typedef unsigned long long ll_word;
-constexpr unsigned LL_FINAL_TAG = 0x7FFFFFFFu;
+constexpr unsigned LL_STEP_BITS = 20;                  // half-steps per launch < 2^20 - 1 (host check: 2 L + 2 < 0xFFFFF)
+constexpr unsigned LL_FINAL_STEP = 0xFFFFFu;
+
+__device__ __forceinline__ unsigned ll_tag_base(const CoopCtrl* c) {
+    const unsigned long long e = __hip_atomic_load(&c->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ((unsigned)e & 0x7FFu) << LL_STEP_BITS;
+}
 
 // local != 0 (one problem per XCD, ll_block): the word is stored with workgroup scope (sc0: it stays in the L2 of the
 // writer's XCD, which every reader of the problem shares; their sc1 loads bypass only their own L1).  Otherwise agent scope
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
     const float log_w = logf(1.0f / (float)n);
     const int nchunk = (n + 255) >> 8;                             // gathering waves
     auto clampi = [&](int e) { const int idx = lane + 64 * e; return idx < n ? idx : n - 1; };   // masked in coop_update
+    const unsigned tbase = ll_tag_base(a.ctrl);                    // this launch's epoch (issued with the matrix loads)
 
     float crow[EPT], ccol[EPT], ov[EPT], ou[EPT];
 #pragma unroll
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
     int nits = 0;
     bool ok = true;
     for (int it = 0; it < a.L; ++it) {
-        const unsigned tagu = 2u * it + 1u, tagv = 2u * it + 2u;
+        const unsigned tagu = tbase + 2u * it + 1u, tagv = tbase + 2u * it + 2u;
         const float un = coop_update<EPT, true>(crow, ov, n, lane, ui, eps, inv_eps, log_w);
         ui = un;
         if (lane == 0 && live) {
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < SC_LINES; ++k) s += red[k];
-        if (ok) ll_store(a.xcost + p * SC_MAXWG + wg, s, LL_FINAL_TAG, local);   // a workgroup that gave up never publishes
+        if (ok) ll_store(a.xcost + p * SC_MAXWG + wg, s, tbase + LL_FINAL_STEP, local);   // a workgroup that gave up never publishes
     }
     if (wg != 0 || w != 0) return;
     // workgroup 0, wave 0: the per-workgroup parts in workgroup order
@@ -283,7 +302,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_fwd_ll(SinkLLArgs a) {
         float val = 0.f;
         while (!dead) {
             const ll_word wv = __hip_atomic_load(a.xcost + p * SC_MAXWG + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            got = (unsigned)(wv >> 32) == LL_FINAL_TAG;
+            got = (unsigned)(wv >> 32) == tbase + LL_FINAL_STEP;
             val = __uint_as_float((unsigned)wv);
             if (__builtin_amdgcn_ballot_w64(!got) == 0) break;
             if ((++spins & 127u) == 0 &&
@@ -350,6 +369,7 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
     const float aconst = eps * logf(1.0f / (float)n);
 
     const int nchunk = (n + 255) >> 8;                             // gathering waves
+    const unsigned tbase = ll_tag_base(a.ctrl);                    // this launch's epoch
     constexpr bool PREFETCH = EPT <= 8;                            // history loads issued ahead of the gathers (registers permitting)
     auto clampi = [&](int e) { const int idx = lane + 64 * e; return idx < n ? idx : n - 1; };
     auto okc = [&](int e) { return live && lane + 64 * e < n; };
@@ -382,9 +402,9 @@ __global__ __launch_bounds__(SC_THREADS) void sinkhorn_bwd_ll(SinkLLBwdArgs a) {
         }
         gu_line = g * wave_sum_fast(su) * inv_eps;
         gv_line = g * wave_sum_fast(sv) * inv_eps;
-        if (lane == 0 && live) ll_store(xgv + line, gv_line, 1u, local);
+        if (lane == 0 && live) ll_store(xgv + line, gv_line, tbase + 1u, local);
     }
-    unsigned tag = 1u;       // the tag of the gv values the next (A) pass reads
+    unsigned tag = tbase + 1u;       // the tag of the gv values the next (A) pass reads
     for (int it = nits; it >= 1; --it) {
         // prefetch this iteration's history (plain loads: written by the forward kernel)
         float vo[PREFETCH ? EPT : 1], uo[PREFETCH ? EPT : 1];
@@ -502,10 +522,18 @@ static int fault_injected() {
 // hipMemsetAsync: as a node of a captured graph the memset's zeros were not what the next node's agent-scope loads saw --
 // the first replay of a graph ran on fresh (zero) memory, every later one found the previous replay's tags, polled to its
 // bound and aborted to NaN (round 3: found when bench.py replayed the configs[3] step as a hipGraph; eager launches were
-// never affected).  tests/test_gpu_parity.py::test_multi_cu_sinkhorn_replays_as_a_graph.
+// never affected; the same symptom in smooth.hip's three scalars).  Whether the memset node lacked its edge or its writes
+// bypassed what the kernels' loads read was not isolated -- a kernel node covers both, and since round 4 a stale word could
+// not be CONSUMED even if one survived: the tags carry the launch epoch (ll_tag_base).
+// tests/test_gpu_parity.py::test_multi_cu_sinkhorn_replays_as_a_graph (replays with different iteration counts).
+// Word LL_EPOCH_WORD (CoopCtrl::epoch) is not zeroed but incremented: whatever the caller's workspace held there before the
+// first launch is as good a start as any -- the tags only have to differ from one launch (or graph replay) to the next.
 __global__ __launch_bounds__(256) void ll_zero(unsigned long long* __restrict__ w, int n64) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n64; i += gridDim.x * 256)
-        __hip_atomic_store(w + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n64; i += gridDim.x * 256) {
+        unsigned long long v = 0ull;
+        if (i == LL_EPOCH_WORD) v = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        __hip_atomic_store(w + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 static int ll_zero_area(void* p, size_t bytes, hipStream_t st) {      // bytes % 8 == 0 (CoopCtrl is 256 bytes, ll_word 8)
     const int n64 = (int)(bytes / 8);

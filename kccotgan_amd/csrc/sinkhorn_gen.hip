@@ -479,6 +479,7 @@ size_t sinkhorn_gen_workspace_bytes(int nprob, int n) {
 }
 
 // sinkhorn_coop.hip
+constexpr int SK_COOP_MAX_L = 500000;
 bool sinkhorn_coop_eligible(int nprob, int n);
 int launch_sinkhorn_fwd_coop(const float* C, int nprob, int n, float eps, int L, int Lmin, float thresh, int stop_mode,
                              float* u_hist, float* v_hist, float* cost_out, int32_t* nits_out, float* pi_out, void* ws,
@@ -492,7 +493,7 @@ int launch_sinkhorn_fwd_gen(const float* C, int nprob, int n, float eps, int L, 
     if (n > SG_MAXN) return fail(KCCOT_EUNSUPPORTED, "sinkhorn_fwd: n=%d > %d", n, SG_MAXN);
     const size_t need = sinkhorn_gen_workspace_bytes(nprob, n);
     if (!ws || ws_bytes < need) return fail(KCCOT_EWORKSPACE, "sinkhorn_fwd: workspace %zu < required %zu", ws_bytes, need);
-    if (sinkhorn_coop_eligible(nprob, n))
+    if (sinkhorn_coop_eligible(nprob, n) && L < SK_COOP_MAX_L)     // the exchange tags hold 2 L + 2 half-steps in 20 bits
         return launch_sinkhorn_fwd_coop(C, nprob, n, eps, L, Lmin, thresh, stop_mode, u_hist, v_hist, cost_out, nits_out, pi_out, ws, st);
     float* CT = static_cast<float*>(ws);
     dim3 tg((n + 31) / 32, (n + 31) / 32, nprob);
@@ -513,7 +514,7 @@ int launch_sinkhorn_bwd_gen(const float* C, const float* u_hist, const float* v_
     if (n > SG_MAXN) return fail(KCCOT_EUNSUPPORTED, "sinkhorn_bwd: n=%d > %d", n, SG_MAXN);
     const size_t need = sinkhorn_gen_workspace_bytes(nprob, n);
     if (!ws || ws_bytes < need) return fail(KCCOT_EWORKSPACE, "sinkhorn_bwd: workspace %zu < required %zu", ws_bytes, need);
-    if (sinkhorn_coop_eligible(nprob, n))
+    if (sinkhorn_coop_eligible(nprob, n) && L < SK_COOP_MAX_L)     // the exchange tags hold 2 L + 2 half-steps in 20 bits
         return launch_sinkhorn_bwd_coop(C, u_hist, v_hist, nits, nprob, n, eps, L, gcost, dC, ws, st);
     float* CT = static_cast<float*>(ws);
     float* dCT = reinterpret_cast<float*>(static_cast<char*>(ws) + need / 2);

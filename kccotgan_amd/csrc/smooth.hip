@@ -1254,8 +1254,11 @@ __global__ __launch_bounds__(256) void conv_axis_adjoint_if(const float* __restr
 }
 
 // {1, 0, 0}: "maximum 1, no arg-max elements" for a plane kernel that runs a plain stencil.  A one-thread KERNEL, not
-// hipMemsetD32Async: memset nodes of a captured graph did not order with the kernel nodes around them on this stack (the
-// second replay of a captured 3-D backward read garbage scalars: NaN; round 3, tests: test_smoothing_replays_as_a_graph).
+// hipMemsetD32Async: as nodes of a captured graph the library's memsets did not take effect for the kernel nodes behind
+// them on this stack (ROCm 7.2) -- the first replay ran on fresh memory and was right, every later one saw the previous
+// replay's words (here: garbage scalars -> NaN in the second replay of a captured 3-D backward; in sinkhorn_coop.hip: the
+// previous replay's exchange tags).  Whether the memset node lacked its edge or its writes bypassed what the kernels' loads
+// read was not isolated; the remedy covers both: a KERNEL writes the words (round 3, test_smoothing_replays_as_a_graph).
 __global__ void set_unit_scalars(float* __restrict__ s) { s[0] = 1.f; s[1] = 0.f; s[2] = 0.f; }
 
 static bool plane_eligible(int T, int W, int C, int radius, int naxes) {

@@ -67,7 +67,7 @@ class HipOps:
         Bl, K = real_l.shape
         out = _lib.empty((Bl, 3), torch.float64, real_l.device)
         ws, wsb = workspace(lib.kccot_row_norms_workspace_bytes(Bl), real_l)
-        check(lib.kccot_row_norms_f64(ptr(real_l), ptr(fake_l), Bl, K, ptr(out), ws, wsb, stream_of(real_l)), "row_norms")
+        check(lib.kccot_row_norms_f64(ptr(real_l), ptr(fake_l), Bl, K, _lib.ptr_f64(out), ws, wsb, stream_of(real_l)), "row_norms")
         return out
 
     @staticmethod
@@ -81,7 +81,7 @@ class HipOps:
         if norms is not None:
             ws, wsb = workspace(lib.kccot_pairwise_cost3_rows_gram_workspace_bytes(row_count, B, K), real)
             check(lib.kccot_pairwise_cost3_rows_gram_f32(ptr(real), ptr(fake), B, K, sc, ptr(h_fake), ptr(h_real), ptr(m_real),
-                                                         ptr(m_fake), T, J, row_begin, row_count, ptr(norms.contiguous()),
+                                                         ptr(m_fake), T, J, row_begin, row_count, _lib.ptr_f64(norms.contiguous()),
                                                          ptr(out), ws, wsb, stream_of(real)), "pairwise_cost3_rows_gram")
             return out
         ws, wsb = workspace(lib.kccot_pairwise_cost3_rows_workspace_bytes(row_count, B, K), real)
@@ -96,15 +96,15 @@ class HipOps:
         or added to `gsum` (kccot_pairwise_cost3_rows_gram_sums_f64)."""
         B, Kc = real_c.shape
         ws, wsb = workspace(lib.kccot_pairwise_cost3_rows_gram_workspace_bytes(row_count, B, Kc), real_c)
-        check(lib.kccot_pairwise_cost3_rows_gram_sums_f64(ptr(real_c), ptr(fake_c), B, Kc, row_begin, row_count, ptr(gsum),
+        check(lib.kccot_pairwise_cost3_rows_gram_sums_f64(ptr(real_c), ptr(fake_c), B, Kc, row_begin, row_count, _lib.ptr_f64(gsum),
                                                           1 if accumulate else 0, ws, wsb, stream_of(real_c)), "rows_gram_sums")
 
     @staticmethod
     def rows_gram_from_sums(gsum, B, h_fake, h_real, m_real, m_fake, sc, row_begin, row_count, norms):
         T, J = h_fake.shape[1], h_fake.shape[2]
         out = _lib.empty((3, row_count, B), torch.float32, gsum.device)
-        check(lib.kccot_pairwise_cost3_rows_gram_from_sums_f32(ptr(gsum), B, sc, ptr(h_fake), ptr(h_real), ptr(m_real), ptr(m_fake),
-                                                               T, J, row_begin, row_count, ptr(norms.contiguous()), ptr(out),
+        check(lib.kccot_pairwise_cost3_rows_gram_from_sums_f32(_lib.ptr_f64(gsum), B, sc, ptr(h_fake), ptr(h_real), ptr(m_real), ptr(m_fake),
+                                                               T, J, row_begin, row_count, _lib.ptr_f64(norms.contiguous()), ptr(out),
                                                                stream_of(gsum)), "rows_gram_from_sums")
         return out
 

@@ -169,3 +169,86 @@ def test_header_is_plain_c_and_the_abi_works_from_c(tmp_path):
     r = subprocess.run([str(exe), os.path.join(ROOT, "kccotgan_amd", "csrc", "libkccot.so")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "abi_smoke ok" in r.stdout
+
+
+# ---- ISA pins of the fence-free hand-offs --------------------------------------------------------
+# Two places exchange data between workgroups WITHOUT fences and are correct because of what the emitted instructions do
+# on gfx950, not because of what the language promises (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
+# inter-workgroup visibility": sc1 stores are written through, sc1 loads bypass the reader's L1 and are served by L2, a
+# plain / sc0 store stays in the writer's XCD L2).  A compiler that changed the cache-policy bits of either access would
+# change correctness, and the bit-equality GPU tests would only notice if a stale read happened to occur.  So the bits
+# themselves are asserted here, on the code the Makefile's flags produce (hipcc cross-compiles without a GPU).
+def _device_isa(name, tmp):
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    out = os.path.join(str(tmp), name.replace(".hip", ".s"))
+    import subprocess
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-o", out,
+                    os.path.join(ROOT, "kccotgan_amd", "csrc", name)], check=True, stderr=subprocess.DEVNULL)
+    kernels, cur, body = {}, None, []
+    for line in open(out):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur, body = m.group(1), []
+            continue
+        if cur is not None:
+            if line.startswith(".Lfunc_end"):
+                kernels[cur] = body
+                cur = None
+            else:
+                body.append(line.strip())
+    return kernels
+
+
+def test_isa_of_the_multi_cu_sinkhorn_exchange(tmp_path):
+    """sinkhorn_coop.hip, ll_store / ll_gather: every 64-bit {value, tag} exchange word is stored EITHER sc0
+    (workgroup scope: stays in the XCD's L2, used only after the in-kernel placement check found every workgroup of the
+    problem on one XCD) OR sc1 (agent scope: written through), never plain and never nt; every polled 64-bit load is sc1
+    (L1 bypassed, L2-served); and the exchange itself holds no fence: the only write-back / invalidates of a kernel are the
+    release / acquire of the one-time placement check (ll_same_xcd)."""
+    kernels = _device_isa("sinkhorn_coop.hip", tmp_path)
+    ll = {k: v for k, v in kernels.items() if "sinkhorn_fwd_ll" in k or "sinkhorn_bwd_ll" in k}
+    assert len(ll) == 6, sorted(kernels)                           # fwd / bwd x EPT 4, 8, 16
+    for name, body in ll.items():
+        st = [l for l in body if l.startswith("global_store_dwordx2")]
+        ld = [l for l in body if l.startswith("global_load_dwordx2")]
+        flags = lambda l: set(l.split()[-2:]) & {"sc0", "sc1", "nt"}
+        assert st and ld, name
+        assert all(flags(l) in ({"sc0"}, {"sc1"}) for l in st), (name, st)
+        n0, n1 = sum(flags(l) == {"sc0"} for l in st), sum(flags(l) == {"sc1"} for l in st)
+        assert n0 == n1 >= 3, (name, n0, n1)                       # each ll_store site: one form per scope
+        assert all(flags(l) == {"sc1"} for l in ld), (name, ld)
+        # (the only flat_ accesses are the volatile reads of the LDS give-up flag; no exchange word travels through one)
+        assert not any(l.startswith(("flat_load_dwordx2", "flat_store", "flat_atomic")) for l in body), name
+        assert sum(l.startswith("buffer_wbl2") for l in body) == 1, name
+        assert sum(l.startswith("buffer_inv") for l in body) == 2, name
+    zero = [v for k, v in kernels.items() if "ll_zero" in k]
+    assert len(zero) == 1 and any(l.startswith("global_store_dwordx2") and l.endswith("sc1") for l in zero[0])
+
+
+def test_isa_of_the_three_cost_hand_off_to_the_combining_workgroup(tmp_path):
+    """sinkhorn.hip, the mixed divergence's combine (gan_utils.py:225) by the last of three workgroups to take a ticket --
+    the first row of the guide's table of measured hand-offs: the handed-off word is stored sc1 by ONE lane, that lane drains
+    its stores (an asm s_waitcnt vmcnt(0) the compiler cannot drop), adds to the agent-scope ticket, and the workgroup whose
+    add returned last reads the three words with sc1 loads after the add has returned.  gfx950 behaviour, not a language
+    guarantee -- hence the pin."""
+    kernels = _device_isa("sinkhorn.hip", tmp_path)
+    seen = 0
+    for name, body in kernels.items():
+        for i, l in enumerate(body):
+            if not l.startswith("global_atomic_add"):
+                continue
+            seen += 1
+            assert l.split()[-1] == "sc0", (name, l)               # returning atomic (the ticket value decides who combines)
+            back, ahead = body[max(0, i - 60):i], body[i:i + 30]
+            drains = [j for j in range(len(back) - 1) if back[j].startswith(";;#ASMSTART") and back[j + 1] == "s_waitcnt vmcnt(0)"]
+            assert drains, name
+            stores = [j for j, b in enumerate(back) if b.startswith("global_store_dword ") and b.endswith("sc1")]
+            assert stores and stores[-1] < drains[-1], (name, back)   # cost word written through BEFORE the drain
+            loads = [b for b in ahead if b.startswith("global_load_dword ")]
+            assert len(loads) == 3 and all(b.endswith("sc1") for b in loads), (name, loads)
+            wait = [j for j, b in enumerate(ahead) if b.startswith("s_waitcnt vmcnt(0)")]
+            first_load = ahead.index(loads[0])
+            assert wait and wait[0] < first_load, name             # the add has returned before the first load issues
+    assert seen >= 6, seen                                         # register forward kernels + fused kernels, every instantiation

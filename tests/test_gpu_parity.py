@@ -174,6 +174,21 @@ def nits_ok(got, g, key):
     return lo - (hi - lo) <= int(got) <= hi + (hi - lo)
 
 
+def test_pointer_guard_refuses_float64_for_float_parameters(G, L):
+    """`_lib.ptr` is the only dtype guard between torch tensors and the `float*` ABI: a float64 tensor must raise instead of
+    being reinterpreted; `ptr_f64` serves the few `double*` parameters (Gram sums, row norms) and refuses fp32."""
+    x64 = torch.zeros(8, dtype=torch.float64, device=DEV)
+    x32 = torch.zeros(8, dtype=torch.float32, device=DEV)
+    with pytest.raises(TypeError):
+        L.ptr(x64)
+    with pytest.raises(TypeError):
+        L.ptr_f64(x32)
+    assert L.ptr(x32) == x32.data_ptr() and L.ptr_f64(x64) == x64.data_ptr() and L.ptr(None) is None
+    # the public entry points CONVERT other float types (as the reference's tf.cast does): never a reinterpretation
+    a = torch.rand(4, 3, 8, dtype=torch.float64, device=DEV)
+    assert torch.equal(G.cost_xy(a, a, 1.0), G.cost_xy(a.float(), a.float(), 1.0))
+
+
 @pytest.mark.parametrize("shape,seed,regime", ALL)
 def test_sinkhorn_variants_match_reference(G, shape, seed, regime):
     g, inp, t = load(shape, seed, regime)
@@ -534,6 +549,43 @@ def test_multi_cu_sinkhorn_replays_as_a_graph(G, L, n):
             g.replay()
         torch.cuda.synchronize()
         assert gn.tolist() == n0.tolist() and torch.equal(gl, l0) and torch.equal(gd, d0), "back-to-back replays"
+
+
+@pytest.mark.parametrize("n", [200, 256])
+def test_multi_cu_sinkhorn_replays_with_changing_iteration_counts(G, L, n):
+    """The case a stale exchange word would corrupt SILENTLY: half-step tags restart at 1 in every launch, so if a word of
+    the previous launch survived the zeroing, a solve that runs LONGER than its predecessor would find valid-looking tags
+    with the predecessor's values.  One captured solve + reverse sweep over a static cost buffer, replayed with contents
+    that stop at 100 (three random problems), at 198 and at 300 iterations (points on a line, gan_utils.py:149-160's
+    Lmin quirk) in the order short, long, short, longest, long: every replay equals the eager run on the same contents bit for
+    bit.  (Round 4: the tags also carry a per-launch epoch that the zeroing kernel increments -- replays included -- so a
+    surviving word could only make a poll run to its bound, never be consumed.)"""
+    from kccotgan_amd.dist import HipOps as H
+    gen = torch.Generator(device=DEV).manual_seed(77 + n)
+    i = torch.arange(n, device=DEV, dtype=torch.float32) / n
+    line = lambda sc: (sc * 2.0 * (i[:, None] - (i[None, :] + 0.5 / n)) ** 2).expand(3, n, n).contiguous()
+    contents = {"short": torch.rand((3, n, n), device=DEV, generator=gen) * 3, "long": line(100.0), "longest": line(300.0)}
+    C3 = torch.empty((3, n, n), device=DEV)
+    one = torch.ones((), device=DEV)
+
+    def step():
+        loss, saved = H.divergence_fwd(C3, 1.0, 300)
+        return loss, H.divergence_bwd(saved, one), saved[3]
+
+    with L.options(sinkhorn_shortcut=0):
+        eager = {}
+        for k, v in contents.items():
+            C3.copy_(v)
+            l, d, nn = step()
+            torch.cuda.synchronize()
+            eager[k] = (l.clone(), d.clone(), nn.tolist())
+        assert eager["short"][2][:3] == [100] * 3 and eager["long"][2][:3] == [198] * 3 and eager["longest"][2][:3] == [300] * 3
+        g, (gl, gd, gn) = _capture(step)
+        for k in ("short", "long", "short", "longest", "long", "longest", "short"):
+            C3.copy_(contents[k])
+            g.replay()
+            torch.cuda.synchronize()
+            assert gn.tolist() == eager[k][2] and torch.equal(gl, eager[k][0]) and torch.equal(gd, eager[k][1]), k
 
 
 @pytest.mark.parametrize("n", [130, 200, 256, 384, 512, 640])
@@ -1319,10 +1371,11 @@ def test_full_size_properties(G, shape, Lc):
     assert float((g2 - g[perm]).abs().max()) < 2e-4 * scale
 
 
-@pytest.mark.parametrize("shape,Lc", FULL_SIZE[2:])
-def test_full_size_configs_3_and_4_against_the_oracle(G, shape, Lc):
-    """BASELINE configs[3] (B = 256, 64x64x3, T = 30, L = 200, + the RBF-MMD extension) and configs[4] (B = 512,
-    128x128x3, T = 48, L = 300) at FULL size on one GPU, oracle-checked where the oracle finishes in seconds:
+@pytest.mark.parametrize("shape,Lc", FULL_SIZE[1:])
+def test_full_size_configs_2_3_and_4_against_the_oracle(G, shape, Lc):
+    """BASELINE configs[2] (B = 128, 64x64x3, T = 30, L = 100: the single-panel 256-row Gram tile `Q256_HALF` at its real
+    K = 368 640, 240 partial tiles), configs[3] (B = 256, 64x64x3, T = 30, L = 200, + the RBF-MMD extension) and configs[4]
+    (B = 512, 128x128x3, T = 48, L = 300) at FULL size on one GPU, oracle-checked where the oracle finishes in seconds:
       * cost matrices: 48 sampled entries + 16 diagonal ones of each of C_xy, C_xx, C_yy against the fp64 oracle
         formula on the two rows involved (K = 368 640 / 2 359 296 terms each) -- the tiled Gram at its real K;
       * Sinkhorn at n = 256 / 512 with L = 200 / 300: the fp64 oracle loop run on the GPU's own cost matrices, cost
@@ -1352,8 +1405,8 @@ def test_full_size_configs_3_and_4_against_the_oracle(G, shape, Lc):
             if i == j and k == 0:        # the near-regime diagonal of C_xy is ~1e-2 of max|C|: check it RELATIVELY too
                 assert abs(C3n[k, i, j] - ref) <= 2e-5 * abs(ref), (i, C3n[k, i, j], ref)
     fk = fake.clone().requires_grad_(True)
-    loss = G.compute_sinkhorn_loss(real, fk, cases.SC, 1.0, Lc, f["h_fake"], f["m_real"], f["h_real"], f["m_fake"],
-                                   honor_eps_l=True)
+    kw = dict(honor_eps_l=True) if Lc != 100 else {}
+    loss = G.compute_sinkhorn_loss(real, fk, cases.SC, 1.0, Lc, f["h_fake"], f["m_real"], f["h_real"], f["m_fake"], **kw)
     nits = G.last_info["compute_sinkhorn_loss"].tolist()[:3]
     w, n_ref = zip(*(o.sinkhorn_from_cost(C3n[k], 1.0, Lc, dtype=np.float64)[:2] for k in range(3)))
     ref_loss = 2.0 * w[0] - w[1] - w[2]
