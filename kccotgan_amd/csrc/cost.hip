@@ -384,7 +384,7 @@ extern "C" int kccot_pairwise_cost3_gram_sums_span(int B, int64_t K, size_t* byt
     *byte_offset = 0; *n_doubles = 0;
     if (B <= 0 || K <= 0 || K % 4 != 0 || K < 256) return 0;
     const bool x3 = !opt(OPT_GRAM_F32);
-    if (B <= 64) gram_sums_span(K, byte_offset, n_doubles);
+    if (B <= 64) gram_sums_span(B, K, byte_offset, n_doubles);
     else if (gram_q256_applies(B, K)) gram_q256_sums_span(B, K, byte_offset, n_doubles);
     else if (x3 && B % 128 == 0 && B <= 4096 && opt(OPT_COST_TILED)) gram_tiled_sums_span(B, K, byte_offset, n_doubles);
     return 0;

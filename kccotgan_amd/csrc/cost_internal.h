@@ -49,6 +49,10 @@ constexpr int CAUSAL_TILE = 16;
 constexpr int CAUSAL_KC = 256;
 constexpr int CAUSAL_PITCH = CAUSAL_KC + 4;   // 260: rows 16-byte aligned and 4 banks apart -> conflict-free ds_read_b128
 
+// MG: rows fetched per pass.  16 = all 48 loads of a k chunk in flight (one memory round trip: the callers on a critical
+// path); 4 = four passes of 12 loads (the spare workgroups of the Gram launch, which finish long before the Gram chunks do:
+// sixteen uniform row bases per operand held at once cost that kernel 72 spilled SGPRs).
+template <int MG = CAUSAL_TILE>
 __device__ __forceinline__ float causal_tile16(const float* __restrict__ h, const float* __restrict__ M, int i0,
                                                int j0, int Bx, int By, int T, int J, float* sh, float* sm,
                                                int t = threadIdx.x) {
@@ -62,19 +66,24 @@ __device__ __forceinline__ float causal_tile16(const float* __restrict__ h, cons
         const int k = k0 + t;
         const bool kok = k < KK;
         const int kc = kok ? k : 0;
-        float hv[CAUSAL_TILE], m0[CAUSAL_TILE], m1[CAUSAL_TILE];
+#pragma unroll 1
+        for (int mb = 0; mb < CAUSAL_TILE; mb += MG) {
+            float hv[MG], m0[MG], m1[MG];
 #pragma unroll
-        for (int m = 0; m < CAUSAL_TILE; ++m) {
-            const int ri = (i0 + m < Bx) ? i0 + m : Bx - 1, rj = (j0 + m < By) ? j0 + m : By - 1;
-            hv[m] = h[(int64_t)ri * TJ + kc];
-            const float* mr = M + (int64_t)rj * TJ + kc;
-            m0[m] = mr[0];
-            m1[m] = mr[J];
-        }
+            for (int q = 0; q < MG; ++q) {
+                const int m = mb + q;
+                const int ri = (i0 + m < Bx) ? i0 + m : Bx - 1, rj = (j0 + m < By) ? j0 + m : By - 1;
+                hv[q] = h[(int64_t)ri * TJ + kc];
+                const float* mr = M + (int64_t)rj * TJ + kc;
+                m0[q] = mr[0];
+                m1[q] = mr[J];
+            }
 #pragma unroll
-        for (int m = 0; m < CAUSAL_TILE; ++m) {
-            sh[m * CAUSAL_PITCH + t] = (kok && i0 + m < Bx) ? hv[m] : 0.f;
-            sm[m * CAUSAL_PITCH + t] = (kok && j0 + m < By) ? m1[m] - m0[m] : 0.f;
+            for (int q = 0; q < MG; ++q) {
+                const int m = mb + q;
+                sh[m * CAUSAL_PITCH + t] = (kok && i0 + m < Bx) ? hv[q] : 0.f;
+                sm[m * CAUSAL_PITCH + t] = (kok && j0 + m < By) ? m1[q] - m0[q] : 0.f;
+            }
         }
         __syncthreads();
 #pragma unroll 8
@@ -125,7 +134,7 @@ size_t gram_tiled_workspace_bytes(int B, int64_t K);
 int run_gram_tiled(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st,
                    int stage = 0);
 void gram_tiled_sums_span(int B, int64_t K, size_t* off, size_t* n);
-void gram_sums_span(int64_t K, size_t* off, size_t* n);
+void gram_sums_span(int B, int64_t K, size_t* off, size_t* n);
 // cost_tile256.hip: batches that are multiples of 256 -- the same Gram in 256 x 256 tiles, E written as a by-product
 bool gram_q256_applies(int B, int64_t K);
 bool gram_q256_eligible(const CostBatch& cb, int64_t K, bool loss3);

@@ -59,12 +59,13 @@ struct GramArgs {
 };
 
 // one 16x16 tile of causal sums by 256 threads (every one of them must call it); sh / sm: LDS scratch
+template <int MG = CAUSAL_TILE>
 __device__ __forceinline__ void causal_pre_tile(const CausalPre& cp, int tile, float* sh, float* sm, int t) {
     const int per = cp.nti * cp.ntj;
     const int slot = tile / per, rem = tile % per;
     if (slot >= 3 || cp.h[slot] == nullptr) return;      // uniform
     const int i0 = (rem / cp.ntj) * CAUSAL_TILE, j0 = (rem % cp.ntj) * CAUSAL_TILE;
-    const float v = causal_tile16(cp.h[slot], cp.M[slot], i0, j0, cp.B1, cp.B2, cp.T, cp.J, sh, sm, t);
+    const float v = causal_tile16<MG>(cp.h[slot], cp.M[slot], i0, j0, cp.B1, cp.B2, cp.T, cp.J, sh, sm, t);
     const int i = i0 + (t >> 4), j = j0 + (t & 15);
     if (i < cp.B1 && j < cp.B2) cp.caus[((int64_t)slot * cp.B1 + i) * cp.B2 + j] = v;
 }
@@ -286,18 +287,25 @@ __device__ __forceinline__ void split3_store(unsigned char* zs, int byte_off, fl
 // One ds_read_b128 moves 1 KB = 8 cycles of the CU's LDS port, one bf16 MFMA keeps a SIMD's matrix
 // pipe busy for 32 cycles and four consumer waves run concurrently: at one fragment read per MFMA
 // (six reads for the six products of a sub-tile, as the single-role kernels do) the LDS port is
-// saturated before the matrix pipes are.  So the 10 sub-tiles (+ 2 half sub-tiles, for balance:
-// 2.5 sub-tiles of MFMA work per SIMD) are dealt to the waves such that the three sub-tiles of a
-// wave SHARE row blocks and every fragment triple (h, m, l) is read once per 16-k step and used by
-// every product that needs it -- 30 reads for 60 MFMAs instead of 60:
+// saturated before the matrix pipes are.  So the 10 sub-tiles (+ 2 half sub-tiles, for balance)
+// are dealt to the waves such that the three sub-tiles of a wave SHARE row blocks and every fragment
+// triple (h, m, l) is read once per 16-k step and used by every product that needs it:
 //     wave W owns row block X = W and its diagonal sub-tile (X,X) (A and B fragments coincide),
 //     an off-diagonal sub-tile with block Y, and one k-half of a sub-tile that pairs X or Y with Z:
-//        W   X  Y  Z   sub-tiles                     slabs
-//        0   0  1  2   (0,0) (0,1) (0,2) k-half 0    0, 1, 2
-//        1   1  2  0   (1,1) (1,2) (0,2) k-half 1    4, 5, 10
-//        2   2  3  1   (2,2) (2,3) (1,3) k-half 0    7, 8, 6
-//        3   3  0  1   (3,3) (0,3) (1,3) k-half 1    9, 3, 11
-// (split sub-tiles 2 and 6 keep their second k-half in slabs 10 and 11: GRAM_SPLIT_26 in gram_reduce).
+//        W   X  Y  Z   sub-tiles
+//        0   0  1  2   (0,0) (0,1) (0,2) k-half 0
+//        1   1  2  0   (1,1) (1,2) (0,2) k-half 1
+//        2   2  3  1   (2,2) (2,3) (1,3) k-half 0
+//        3   3  0  1   (3,3) (0,3) (1,3) k-half 1
+//
+// Round 4:
+//  * A DIAGONAL sub-tile is symmetric, and of its six split products hh and mm are symmetric themselves while mh = (hm)^T and
+//    lh = (hl)^T.  The wave accumulates S = mm + hh and A = hl + hm in two accumulators (FOUR products per 16 k instead of
+//    six: 52 instead of 60 MFMAs per stage and SIMD) and forms  G = S + A + A^T  once per workgroup, through LDS.
+//  * The two k-halves of the split sub-tiles are added in LDS before anything is stored, the diagonal sub-tiles are stored as
+//    packed upper triangles, and the whole partial leaves the CU as ONE contiguous 33 KB record written with 16-byte
+//    stores by all consumer threads:  12 slabs x 4 KB = 48 KB per chunk  ->  8256 floats (GRAM_CPT) -- 11.8 MB -> 7.9 MB of
+//    partial tiles at configs[1], for the store AND for gram_reduce's read.
 struct Frag3 { bf16x8 h, m, l; };
 
 __device__ __forceinline__ Frag3 ld_frag3(const unsigned char* zs, int off) {
@@ -318,33 +326,46 @@ __device__ __forceinline__ void mfma_x3(f32x16& acc, const Frag3& A, const Frag3
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h, acc, 0, 0, 0);
 }
 
-__device__ __forceinline__ void store_tile(float* base, int slab, int lane, const f32x16& acc) {
+// diagonal sub-tile: S += mm + hh (symmetric products), A += hl + hm (their transposes are the two products left out)
+__device__ __forceinline__ void mfma_x3_diag(f32x16& accS, f32x16& accA, const Frag3& F) {
+    accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.m, F.m, accS, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h, F.l, accA, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h, F.m, accA, 0, 0, 0);
+    accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h, F.h, accS, 0, 0, 0);
+}
+
+// Compact partial record of one K-chunk (floats): the six off-diagonal sub-tiles (a < b) row-major [32][32] at
+// gram_od(a, b) * 1024, then the four diagonal sub-tiles as packed upper triangles (528 each) at 6144 + 528 a.
+constexpr int GRAM_TRI = 528;
+constexpr int GRAM_CPT = 6 * 1024 + 4 * GRAM_TRI;        // 8256 = 129 * 64
+static_assert(GRAM_CPT % 64 == 0 && GRAM_CPT * 4 <= 3 * XPLANE, "one 256-byte line per reducing wave; fits a stage buffer");
+__host__ __device__ __forceinline__ int gram_od(int a, int b) { return a == 0 ? b - 1 : (a == 1 ? b + 1 : 5); }
+__host__ __device__ __forceinline__ int gram_tri(int r, int c) { return r * 32 - ((r * (r - 1)) >> 1) + (c - r); }   // r <= c
+
+// accumulator register r of lane l is element ((r&3) + 8*(r>>2) + 4*(l>>5), l&31)
+__device__ __forceinline__ void img_tile(float* img, int od, int lane, const f32x16& acc) {
     const int col = lane & 31, rbase = 4 * (lane >> 5);
-    float* o = base + slab * 1024;
+    float* o = img + od * 1024;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + rbase) * 32 + col] = acc[r];
 }
 
 template <int W>
-__device__ __forceinline__ void x3ws_consume(const unsigned char* zsA, const unsigned char* zsB, int nstage, int lane,
-                                             float* base) {
+__device__ __forceinline__ void x3ws_consume(unsigned char* zsA, unsigned char* zsB, int nstage, int lane, float* out) {
     constexpr int X = W, Y = (W + 1) & 3, Z = (W == 0) ? 2 : (W == 1 ? 0 : 1);
     constexpr int KB0 = (W & 1) * 2;                           // the k-half of the stage this wave takes of its split sub-tile
-    constexpr int SLAB1 = (W == 0) ? 0 : (W == 1 ? 4 : (W == 2 ? 7 : 9));
-    constexpr int SLAB2 = (W == 0) ? 1 : (W == 1 ? 5 : (W == 2 ? 8 : 3));
-    constexpr int SLAB3 = (W == 0) ? 2 : (W == 1 ? 10 : (W == 2 ? 6 : 11));
     const int lo = (lane & 31) * XPITCH + 16 * (lane >> 5);    // row (lane&31), k half (lane>>5) of a 16-k block
     const int ox = X * 32 * XPITCH + lo, oy = Y * 32 * XPITCH + lo, oz = Z * 32 * XPITCH + lo;
-    f32x16 acc0, acc1, acc2;
+    f32x16 accS, accA, acc1, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { accS[r] = 0.f; accA[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
     __syncthreads();                                  // stage 0 is in buffer A
     for (int s = 0; s < nstage; ++s) {
         const unsigned char* zs = (s & 1) ? zsB : zsA;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             const Frag3 fx = ld_frag3(zs, ox + kb * 32), fy = ld_frag3(zs, oy + kb * 32);
-            mfma_x3(acc0, fx, fx);
+            mfma_x3_diag(accS, accA, fx);
             if (W != 3) mfma_x3(acc1, fx, fy); else mfma_x3(acc1, fy, fx);      // (X,Y), or (0,3) = (Y,X) for W = 3
             if (kb >= KB0 && kb < KB0 + 2) {
                 const Frag3 fz = ld_frag3(zs, oz + kb * 32);
@@ -355,9 +376,46 @@ __device__ __forceinline__ void x3ws_consume(const unsigned char* zsA, const uns
         }
         __syncthreads();                              // stage s consumed; stage s+1 is complete
     }
-    store_tile(base, SLAB1, lane, acc0);
-    store_tile(base, SLAB2, lane, acc1);
-    store_tile(base, SLAB3, lane, acc2);
+    // ---- epilogue: the producers have left (their barrier count is complete); both stage buffers are free.
+    // zsA: the compact record (33 KB).  zsB: per-wave transpose scratch [32][33] floats, then the two k-half hand-overs.
+    float* img = reinterpret_cast<float*>(zsA);
+    float* tr = reinterpret_cast<float*>(zsB) + W * (32 * 33);
+    float* half = reinterpret_cast<float*>(zsB) + 4 * (32 * 33) + (W >> 1) * 1024;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    if (W & 1) {                                       // second k-half: same lane <-> element map as the first half's wave
+#pragma unroll
+        for (int r = 0; r < 16; ++r) half[r * 64 + lane] = acc2[r];
+    }
+    // G = S + A + A^T of the diagonal sub-tile, upper triangle only
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + rbase) * 33 + col] = accA[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        float* o = img + 6 * 1024 + X * GRAM_TRI;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + rbase;
+            const float g = (accS[r] + accA[r]) + tr[col * 33 + row];
+            if (row <= col) o[gram_tri(row, col)] = g;
+        }
+    }
+    img_tile(img, (W == 0) ? gram_od(0, 1) : (W == 1 ? gram_od(1, 2) : (W == 2 ? gram_od(2, 3) : gram_od(0, 3))), lane, acc1);
+    __syncthreads();                                  // the second halves are in LDS
+    if (!(W & 1)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] += half[r * 64 + lane];
+        img_tile(img, (W == 0) ? gram_od(0, 2) : gram_od(1, 3), lane, acc2);
+    }
+    __syncthreads();                                  // the record is complete
+    // 8256 floats = 2064 float4 by the 256 consumer threads, contiguous 16-byte stores
+    const int ct = W * 64 + lane;
+    const float4* src = reinterpret_cast<const float4*>(img);
+    float4* dst = reinterpret_cast<float4*>(out);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[ct + 256 * i] = src[ct + 256 * i];
+    if (ct < GRAM_CPT / 4 - 2048) dst[ct + 2048] = src[ct + 2048];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -472,7 +530,7 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
         float* sh = reinterpret_cast<float*>(zsA);
         float* sm = sh + CAUSAL_TILE * CAUSAL_PITCH;
         for (int tile = blockIdx.x - ga.nchunk; tile < ga.ntiles; tile += gridDim.x - ga.nchunk)
-            causal_pre_tile(ga.cp, tile, sh, sm, t);
+            causal_pre_tile<4>(ga.cp, tile, sh, sm, t);
         return;
     }
     const int64_t kbeg = (int64_t)blockIdx.x * ga.chunk;
@@ -487,12 +545,12 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
     }
 
     // ---------------------------------------------------------------------- consumers
-    float* base = ga.gpart + (int64_t)blockIdx.x * GRAM_SLABS * 1024;
+    float* out = ga.gpart + (int64_t)blockIdx.x * GRAM_CPT;      // this chunk's compact record
     switch (wave - 4) {
-        case 0: x3ws_consume<0>(zsA, zsB, nstage, lane, base); break;
-        case 1: x3ws_consume<1>(zsA, zsB, nstage, lane, base); break;
-        case 2: x3ws_consume<2>(zsA, zsB, nstage, lane, base); break;
-        default: x3ws_consume<3>(zsA, zsB, nstage, lane, base); break;
+        case 0: x3ws_consume<0>(zsA, zsB, nstage, lane, out); break;
+        case 1: x3ws_consume<1>(zsA, zsB, nstage, lane, out); break;
+        case 2: x3ws_consume<2>(zsA, zsB, nstage, lane, out); break;
+        default: x3ws_consume<3>(zsA, zsB, nstage, lane, out); break;
     }
 }
 
@@ -508,7 +566,7 @@ __global__ __launch_bounds__(512) void gram128_partial_x3ws(GramArgs ga) {
 // gram_finalize then only gathers and adds -- its dependent chain (launch -> Gram gathers -> feature
 // loads -> LDS dot products) was as long as the whole reduction.
 
-enum { GRAM_SPLIT_NONE = 0, GRAM_SPLIT_89 = 1, GRAM_SPLIT_26 = 2 };
+enum { GRAM_SPLIT_NONE = 0, GRAM_SPLIT_89 = 1 };
 
 __global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gpart, int nchunk, unsigned mask, int split_mode,
                                                     double* __restrict__ gsum, CausalPre cp) {
@@ -525,8 +583,7 @@ __global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gp
     const int sub = e >> 10;
     const bool need = (mask >> sub) & 1u;
     // sub-tiles whose k-groups are shared by two waves keep the second half in slab 10 / 11
-    const int second = (split_mode == GRAM_SPLIT_89 && sub >= 8) ? sub + 2
-                     : (split_mode == GRAM_SPLIT_26 && (sub == 2 || sub == 6)) ? (sub == 2 ? 10 : 11) : -1;
+    const int second = (split_mode == GRAM_SPLIT_89 && sub >= 8) ? sub + 2 : -1;
     const bool split = second >= 0;
     const int soff = split ? (second - sub) * 1024 : 0;
     double s = 0.0;
@@ -557,8 +614,37 @@ __global__ __launch_bounds__(1024) void gram_reduce(const float* __restrict__ gp
     }
 }
 
+// The same for the compact records of gram128_partial_x3ws ([nchunk][GRAM_CPT] floats, no split slabs): entry e of every
+// chunk, one 256-byte line per wave and chunk.  Thread (e = t & 63, grp = t >> 6) owns chunks grp, grp + 16, ... (at most 16
+// of them: nchunk <= 256) and has ALL of its loads in flight before the first add -- one memory round trip instead of four
+// (round 3's loop kept four chunks in flight: 5.3 us for 11.8 MB; the work is one pass over 7.9 MB now).  Unconditional loads at
+// clamped chunk indices, out-of-range values replaced by zeros: adds in chunk order, run-to-run deterministic as before.
+__global__ __launch_bounds__(1024) void gram_reduce_compact(const float* __restrict__ gpart, int nchunk, double* __restrict__ gsum) {
+    __shared__ double part[16][64];
+    const int t = threadIdx.x, el = t & 63, grp = t >> 6;
+    const float* p = gpart + blockIdx.x * 64 + el;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = grp + 16 * q;
+        v[q] = p[(int64_t)(c < nchunk ? c : nchunk - 1) * GRAM_CPT];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += (grp + 16 * q < nchunk) ? (double)v[q] : 0.0;
+    part[grp][el] = s;
+    __syncthreads();
+    if (grp == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) tot += part[g][el];
+        gsum[blockIdx.x * 64 + el] = tot;
+    }
+}
+
 struct GramFin {
     const double* gsum;
+    int compact;         // gsum holds GRAM_CPT entries in the compact record's order (gram128_partial_x3ws), else slabs
     int mode;
     int B1, B2;          // output rows / cols
     float* out[3];
@@ -573,15 +659,22 @@ struct GramFin {
     float* out_t;        // GRAM_XY only: blockIdx.z == 1 writes the transposed distances + the (h2, M2) causal term here
 };
 
+template <bool COMPACT>
 __device__ __forceinline__ double gram_at(const double* __restrict__ gsum, int s, int t) {
     // branch-free (selects): only sub-tiles on/above the diagonal are stored
     const bool sw = (s >> 5) > (t >> 5);
     const int s2 = sw ? t : s, t2 = sw ? s : t;
-    return gsum[sub_index(s2 >> 5, t2 >> 5) * 1024 + (s2 & 31) * 32 + (t2 & 31)];
+    if (!COMPACT) return gsum[sub_index(s2 >> 5, t2 >> 5) * 1024 + (s2 & 31) * 32 + (t2 & 31)];
+    // compact record: off-diagonal sub-tiles whole, diagonal ones as packed upper triangles
+    const int a = s2 >> 5, b = t2 >> 5, r = s2 & 31, c = t2 & 31;
+    const int rr = r < c ? r : c, cc = r < c ? c : r;
+    const int off = gram_od(a, b) * 1024 + r * 32 + c, dia = 6 * 1024 + a * GRAM_TRI + gram_tri(rr, cc);
+    return gsum[a == b ? dia : off];
 }
 
 // One 16x16 output tile per block: distances from the summed Gram entries (fp64), scale, causal term.
-__global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
+template <bool COMPACT>
+__device__ __forceinline__ void gram_finalize_body(const GramFin& f) {
     const int p = blockIdx.z;
     const int i0 = blockIdx.y * CAUSAL_TILE, j0 = blockIdx.x * CAUSAL_TILE;
     const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
@@ -594,10 +687,10 @@ __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
     const float cb = (p == 0 && f.h2 && !f.out_t) ? f.caus[plane + at] : 0.f;
     double D;
     if (f.mode == GRAM_LOSS3) {
-        const double g_ii = gram_at(G, ii, ii), g_jj = gram_at(G, jj, jj), g_ij = gram_at(G, ii, jj);
-        const double e_ii = gram_at(G, 64 + ii, 64 + ii), e_jj = gram_at(G, 64 + jj, 64 + jj), e_ij = gram_at(G, 64 + ii, 64 + jj);
-        const double x_ii = gram_at(G, ii, 64 + ii), x_jj = gram_at(G, jj, 64 + jj);
-        const double x_ij = gram_at(G, ii, 64 + jj), x_ji = gram_at(G, jj, 64 + ii);
+        const double g_ii = gram_at<COMPACT>(G, ii, ii), g_jj = gram_at<COMPACT>(G, jj, jj), g_ij = gram_at<COMPACT>(G, ii, jj);
+        const double e_ii = gram_at<COMPACT>(G, 64 + ii, 64 + ii), e_jj = gram_at<COMPACT>(G, 64 + jj, 64 + jj), e_ij = gram_at<COMPACT>(G, 64 + ii, 64 + jj);
+        const double x_ii = gram_at<COMPACT>(G, ii, 64 + ii), x_jj = gram_at<COMPACT>(G, jj, 64 + jj);
+        const double x_ij = gram_at<COMPACT>(G, ii, 64 + jj), x_ji = gram_at<COMPACT>(G, jj, 64 + ii);
         const bool diag = ii == jj;
         const double dxx = diag ? 0.0 : g_ii + g_jj - 2.0 * g_ij;
         const double dxy = dxx + e_jj - 2.0 * (x_ij - x_jj);
@@ -605,9 +698,9 @@ __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
         const double dyy = diag ? 0.0 : dxx + dee + 2.0 * (x_ii - x_ij - x_ji + x_jj);
         D = (p == 1) ? dxx : (p == 0 ? dxy : dyy);
     } else if (f.mode == GRAM_XY) {
-        D = gram_at(G, ii, ii) + gram_at(G, 64 + jj, 64 + jj) - 2.0 * gram_at(G, ii, 64 + jj);
+        D = gram_at<COMPACT>(G, ii, ii) + gram_at<COMPACT>(G, 64 + jj, 64 + jj) - 2.0 * gram_at<COMPACT>(G, ii, 64 + jj);
     } else {  // GRAM_SAME: row i of x is stack row i (rows 64.. come from src2 = x + 64 rows)
-        const double g_ii = gram_at(G, ii, ii), g_jj = gram_at(G, jj, jj), g_ij = gram_at(G, ii, jj);
+        const double g_ii = gram_at<COMPACT>(G, ii, ii), g_jj = gram_at<COMPACT>(G, jj, jj), g_ij = gram_at<COMPACT>(G, ii, jj);
         D = (ii == jj) ? 0.0 : g_ii + g_jj - 2.0 * g_ij;
     }
     if (D < 0.0) D = 0.0;   // a squared distance; rounding of the Gram terms may leave -tiny
@@ -622,6 +715,10 @@ __global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
     if (f.h[p]) c += ca * f.sc;
     if (p == 0 && f.h2) c += cb * f.sc;
     if (ok) f.out[p][(int64_t)i * f.pitch + j] = c;
+}
+
+__global__ __launch_bounds__(256) void gram_finalize(GramFin f) {
+    if (f.compact) gram_finalize_body<true>(f); else gram_finalize_body<false>(f);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -682,10 +779,11 @@ static unsigned gram_mask(int mode, int n1, int n2) {
     return m;
 }
 
-void gram_sums_span(int64_t K, size_t* off, size_t* n) {
+void gram_sums_span(int B, int64_t K, size_t* off, size_t* n) {
     const GramPlan pl = plan_gram(K);
     *off = pl.gpart_bytes;
-    *n = GRAM_ELEMS;
+    // more than 32 rows per operand: all ten sub-tiles, and on the bf16 pipe the compact record (run_gram)
+    *n = (B > 32 && gram_use_x3()) ? GRAM_CPT : GRAM_ELEMS;
 }
 
 // stage 0: everything; 1: stop after the fp64 Gram sums and the causal sums are in the workspace; 2: finalize only
@@ -695,6 +793,7 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     if (!ws || ws_bytes < pl.ws_bytes)
         return fail(KCCOT_EWORKSPACE, "pairwise_cost(mfma): workspace %zu < required %zu", ws_bytes, pl.ws_bytes);
     if (pl.nchunk > 1024) return fail(KCCOT_EUNSUPPORTED, "pairwise_cost(mfma): %d chunks", pl.nchunk);
+    if (pl.nchunk > 256) return fail(KCCOT_EUNSUPPORTED, "pairwise_cost(mfma): %d chunks (the reduction holds 16 x 16)", pl.nchunk);
     GramArgs ga{};
     GramFin gf{};
     const CostProb& p0 = cb.p[0];
@@ -741,27 +840,32 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     int ncausal = nslot * cp.nti * cp.ntj;                  // tiles still to be done by gram_reduce's extra workgroups
     ga.nchunk = pl.nchunk; ga.ntiles = 0; ga.cp = cp;
     int split_mode = (ga.mask == 0x3FFu) ? GRAM_SPLIT_89 : GRAM_SPLIT_NONE;
+    const bool compact = ga.mask == 0x3FFu && gram_use_x3();   // gram128_partial_x3ws writes compact records
+    gf.compact = compact ? 1 : 0;
     if (stage == 2) {
         gf.gsum = gsum; gf.caus = cp.caus; gf.mode = mode; gf.sc = sc; gf.T = T; gf.J = J;
         hipLaunchKernelGGL(gram_finalize, dim3((gf.B2 + CAUSAL_TILE - 1) / CAUSAL_TILE, (gf.B1 + CAUSAL_TILE - 1) / CAUSAL_TILE, nout),
                            dim3(256), 0, st, gf);
         return launch_status("gram_finalize");
     }
-    if (ga.mask == 0x3FFu && gram_use_x3()) {
+    if (compact) {
         // 16 spare workgroups (one per CU the 240-way K-split leaves idle) take the causal tiles
         int spare = 0;
         if (ncausal > 0 && !partial_only) { spare = ncausal < 16 ? ncausal : 16; ga.ntiles = ncausal; ncausal = 0; }
         // (producers with two stages of unconditional clamped loads in flight: 19.1-20.4 us against 21.0-21.8 us for one
         // stage of predicated loads, profiles/r02x_ab_gram_producers.txt)
         hipLaunchKernelGGL(gram128_partial_x3ws, dim3(pl.nchunk + spare), dim3(512), 0, st, ga);
-        split_mode = GRAM_SPLIT_26;
     }
     else if (ga.mask == 0x3FFu) hipLaunchKernelGGL(gram128_partial<true>, dim3(pl.nchunk), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL(gram128_partial<false>, dim3(pl.nchunk), dim3(256), 0, st, ga);
     int rc = launch_status("gram128_partial");
     if (rc || partial_only) return rc;
-    hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 64 + ncausal), dim3(1024), 0, st,
-                       (const float*)ga.gpart, pl.nchunk, ga.mask, split_mode, gsum, cp);
+    if (compact)
+        // (its causal tiles ran in the spare workgroups of the Gram launch: ncausal == 0 here)
+        hipLaunchKernelGGL(gram_reduce_compact, dim3(GRAM_CPT / 64), dim3(1024), 0, st, (const float*)ga.gpart, pl.nchunk, gsum);
+    else
+        hipLaunchKernelGGL(gram_reduce, dim3(GRAM_ELEMS / 64 + ncausal), dim3(1024), 0, st,
+                           (const float*)ga.gpart, pl.nchunk, ga.mask, split_mode, gsum, cp);
     rc = launch_status("gram_reduce");
     if (rc || stage == 1) return rc;
     gf.gsum = gsum; gf.caus = cp.caus; gf.mode = mode; gf.sc = sc; gf.T = T; gf.J = J;
