@@ -1191,9 +1191,11 @@ def test_one_call_loss_equals_staged_path(G, L):
     """The one-call loss entry points (cost assembly + fused solve/sweep, or the two-kernel sequence where the history
     does not fit LDS) against _Cost3 followed by _SinkhornDivergence: bit-identical values and gradients.  (The
     staged reverse sweep is pinned to the fused kernel's 8 lanes per line for 32 < n <= 64, where it defaults to 16:
-    another summation order of the same terms otherwise.)"""
+    another summation order of the same terms otherwise.)  Batches that take the slab layout of the Gram partials (B = 8,
+    16: at most 32 rows per operand) and the compact record of round 4 (B = 64, decimated and full K): loss, gradients
+    AND the three cost matrices the call leaves behind."""
     L.set_option("sinkhorn_lanes_per_line", 8)
-    for shape, seed, regime in (SMALL[0], ("cfg2", 1, "far")):
+    for shape, seed, regime in (SMALL[0], ("small", 1, "far"), ("deci64", 0, "near"), ("cfg1", 1, "far"), ("cfg2", 1, "far")):
         g, inp, t = load(shape, seed, regime)
         wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]
         outs = []
@@ -1202,14 +1204,15 @@ def test_one_call_loss_equals_staged_path(G, L):
             if fused:
                 loss = G.compute_sinkhorn_loss(tt["real"], tt["fake"], cases.SC, 0.8, 100, tt["h_fake"], tt["m_real"],
                                                tt["h_real"], tt["m_fake"], video=True)
+                C3 = G.last_info["compute_sinkhorn_loss_C3"].clone()
             else:
                 C3 = G._Cost3.apply(G._flat2(tt["real"]), G._flat2(tt["fake"]), G._feat(tt["h_fake"]), G._feat(tt["h_real"]),
                                     G._feat(tt["m_real"]), G._feat(tt["m_fake"]), float(cases.SC))
                 loss = G._SinkhornDivergence.apply(C3, 1.0, 100, 100, "staged")
             grads = torch.autograd.grad(loss, [tt[k] for k in wrt])
-            outs.append([loss.detach().reshape(1)] + [x.reshape(-1) for x in grads])
+            outs.append([loss.detach().reshape(1), C3.detach().reshape(-1)] + [x.reshape(-1) for x in grads])
         for a, b in zip(*outs):
-            assert _same_bits(a.cpu().numpy(), b.cpu().numpy())
+            assert _same_bits(a.cpu().numpy(), b.cpu().numpy()), (shape, seed, regime)
 
 
 def test_graphed_loss_is_bit_identical(G, L):

@@ -43,7 +43,7 @@ def timed(fn, n, warm=10):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-out = {"lib": os.path.basename(_lib.LIB_PATH), "version": int(lib.kccot_version())}
+out = {"lib": os.path.basename(_lib.LIB_PATH), "options": os.environ.get("KCCOT_OPTIONS", ""), "version": int(lib.kccot_version())}
 out["partial_us"] = timed(lambda: launch(_lib.COST_PARTIAL_ONLY), reps)
 out["stage_eager_us"] = timed(lambda: launch(0), reps)
 side = torch.cuda.Stream(device=dev)

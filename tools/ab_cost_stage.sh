@@ -7,7 +7,8 @@ TAG=${1:-ab}; shift
 LIBS=("$@"); [ ${#LIBS[@]} -eq 0 ] && LIBS=(kccotgan_amd/csrc/libkccot_base.so kccotgan_amd/csrc/libkccot.so)
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 for round in 1 2 3; do
-  for l in "${LIBS[@]}"; do
-    KCCOT_LIB_PATH="$PWD/$l" timeout -k 10 200 python tools/ab_cost_stage.py 200 2>>"$OUT/err.log" | tee -a "$OUT/ab.jsonl" || exit $?
+  for entry in "${LIBS[@]}"; do          # "path" or "path:name=value,name=value" (KCCOT_OPTIONS for that run)
+    l=${entry%%:*}; o=""; [ "$l" != "$entry" ] && o=${entry#*:}
+    KCCOT_OPTIONS="$o" KCCOT_LIB_PATH="$PWD/$l" timeout -k 10 200 python tools/ab_cost_stage.py 200 2>>"$OUT/err.log" | tee -a "$OUT/ab.jsonl" || exit $?
   done
 done
