@@ -4,6 +4,7 @@ message types declared here from the public ``tf.train`` schema (example.proto /
 framing with ``zlib``-free CRC-32C from its published test vector -- so the hand-written wire parser of
 ``kccotgan_amd/tfrecord.py`` is checked against the library everyone else uses, not against itself."""
 import io
+import os
 import struct
 
 import numpy as np
@@ -175,3 +176,53 @@ def test_gqn_reader_layout_and_file_names(tmp_path):
     np.testing.assert_allclose(small, blk.transpose(1, 0, 2, 3), rtol=0, atol=1e-6)
     with pytest.raises(ValueError, match="Maximum support context size"):
         next(datasets.gqn_videos([str(path)], "shepard_metzler_5_parts", time_steps=16))
+
+
+# ---- fixtures from an INDEPENDENT writer (tests/golden/make_tfrecord_golden.py: bytes assembled by hand, bit-at-a-time CRC-32C
+# checked against RFC 3720's vectors; no protobuf runtime, none of this package's code) ------------------------------------
+GOLD_TF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tfrecord")
+
+
+def test_readers_on_hand_assembled_bair_records():
+    """data_utils.py:63-104 on records in the layout of the real BAIR files: tf.train.Example messages (the reference parses
+    them as SequenceExample and reads .context -- field 1 either way) with '<i>/image_aux1/encoded' raw uint8 frames among
+    other features, map entries in arbitrary order and in both key/value orders, packed and unpacked floats, a negative
+    int64, an empty Feature; both checksums of every record verified."""
+    exp = np.load(os.path.join(GOLD_TF, "tfrecord_expected.npz"))
+    path = os.path.join(GOLD_TF, "bair_softmotion.tfrecord")
+    recs = list(tfrecord.records(path, verify_payload=True))
+    assert [len(r) for r in recs] == exp["bair_payload_bytes"].tolist()
+    ctx, lists = tfrecord.parse_sequence_example(recs[0])
+    assert lists == {} and len(ctx) == 4 * 30 + 2
+    assert ctx["meta/ids"].tolist() == [0, -1, 1 << 40] and ctx["meta/empty"] == []
+    assert ctx["3/endeffector_pos"].shape == (3,) and ctx["3/action"].shape == (4,)          # unpacked / packed floats
+    assert tfrecord.parse_example(recs[1])["meta/ids"].tolist() == [1, -1, 1 << 40]          # unpacked varints
+    out = list(datasets.robot_push_videos([path], T=20, img_shape=(16, 16, 3)))
+    assert len(out) == 2
+    for frames, o in zip(exp["bair_frames"], out):
+        assert o.shape == (16, 20, 16, 3) and o.dtype == np.float64
+        np.testing.assert_array_equal(o, (frames.transpose(1, 0, 2, 3) / 255.0)[:, :20])
+    with pytest.raises(ValueError, match="expected"):                                      # the default 64 x 64 x 3 does not fit
+        next(datasets.robot_push_videos([path]))
+
+
+def test_readers_on_hand_assembled_gqn_records():
+    """data_utils.py:355-449 on records in the layout of the GQN shepard_metzler_5_parts files ('frames': 15 JPEG strings,
+    'cameras': 75 floats, the map entry of 'cameras' written value first): float32 in [0, 1], [H, T, W, C], first T views,
+    the file name the reference's template produces; bilinear resize to a custom frame size."""
+    exp = np.load(os.path.join(GOLD_TF, "tfrecord_expected.npz"))
+    names = datasets.gqn_files("shepard_metzler_5_parts", GOLD_TF, "train")
+    assert os.path.basename(names[0]) == "001-of-900.tfrecord" and len(names) == 900      # data_utils.py:343-346
+    path = os.path.join(GOLD_TF, "001-of-900.tfrecord")
+    recs = list(tfrecord.records(path, verify_payload=True))
+    assert [len(r) for r in recs] == exp["gqn_payload_bytes"].tolist()
+    ex = tfrecord.parse_example(recs[0])
+    assert len(ex["frames"]) == 15 and ex["cameras"].shape == (75,) and ex["frames"][0][:2] == b"\xff\xd8"   # JPEG SOI
+    out = list(datasets.gqn_videos([path], "shepard_metzler_5_parts", 10))
+    assert len(out) == 2
+    for pix, o in zip(exp["gqn_pixels"], out):
+        assert o.shape == (64, 10, 64, 3) and o.dtype == np.float32
+        np.testing.assert_array_equal(o, (pix[:10].astype(np.float32) * np.float32(1 / 255.0)).transpose(1, 0, 2, 3))
+    small = next(datasets.gqn_videos([path], "shepard_metzler_5_parts", 4, custom_frame_size=32))
+    blk = (exp["gqn_pixels"][0][:4].astype(np.float32) / 255.0).reshape(4, 32, 2, 32, 2, 3).mean((2, 4))    # 2x2 box = bilinear at 1/2
+    np.testing.assert_allclose(small, blk.transpose(1, 0, 2, 3), atol=1e-6)
