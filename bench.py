@@ -35,6 +35,7 @@ Prints ONE JSON line (rank 0).
 import argparse
 import json
 import os
+import signal
 import subprocess
 import sys
 import time
@@ -454,41 +455,135 @@ def time_smoothing(dev):
     return out
 
 
-def sharded_config(name, rank, world, dev, dist, barrier, steps=5):
-    """The batch-sharded step (kccotgan_amd.dist) of the BASELINE config that names this GPU count, global batch fixed
-    (strong scaling of that config), timed with EVERY protocol the shape supports: `gather` (all-gather the batch, row
-    blocks on the matrix pipe -- what BASELINE.json's north star prescribes) and `ksplit` (all-to-all into K-slices,
-    all-reduced fp64 Gram sums).  Neither has been timed on more than one GPU before the first SCALE run: the record of
-    both is what decides the default."""
+def _all_ok(ok, dev, dist):
+    """True only if EVERY rank succeeded (one rank failing alone -- out of memory, a workspace -- must not leave the others
+    blocked in the next barrier: all ranks learn it here and skip the timed region together)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag) == 1
+
+
+def _max_over_ranks(x, dev, dist):
+    tt = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt)
+
+
+def sharded_shape(tag, B, H, T, W, C, L, rank, world, dev, dist, barrier, steps=5):
+    """The batch-sharded loss step (kccotgan_amd.dist) of ONE global shape on `world` ranks, timed with EVERY protocol the
+    shape supports -- `gather` (all-gather the batch, row blocks on the matrix pipe: what BASELINE.json's north star
+    prescribes), `gather_chunks` (the same with the videos travelling as 4 column ranges, Gram sums accumulated behind the
+    arrivals) and `ksplit` (all-to-all into K-slices, all-reduced fp64 Gram sums) -- and, per protocol, the device time of
+    each phase (max over ranks, ms per step: input exchange, cost rows, cost exchange, Sinkhorn forward / reverse sweep,
+    gradient rows; kccotgan_amd.dist.phase_ms) so that the curve can be read against DESIGN.md section 6's table."""
     from kccotgan_amd import dist as kd
-    B, H, T, W, C, L, ngpu = OTHER_CONFIGS[name]
     Bl = B // world
     K = H * T * W * C
     t = config_inputs(Bl, H, T, W, C, dev, seed=100 + rank)       # this rank's shard only
     shard = {k: v.requires_grad_(k != "real") for k, v in t.items()}
-    protocols = ["gather"] + (["ksplit"] if kd.ksplit_supported(B, K, world) else [])
-    rec = {"B": B, "K": K, "L": L, "n_gpus_here": world, "steps": steps, "protocols": {}}
-    for proto in protocols:
+    protocols = [("gather", "gather", None)]
+    if B > 64 and K >= 4096:
+        protocols.append(("gather_chunks", "gather", "4"))
+    if kd.ksplit_supported(B, K, world):
+        protocols.append(("ksplit", "ksplit", None))
+    rec = {"B": B, "per_rank_B": Bl, "K": K, "L": L, "n_gpus_here": world, "steps": steps, "protocols": {}}
+    for label, proto, chunks in protocols:
+        if chunks:
+            os.environ["KCCOT_DIST_GATHER_CHUNKS"] = chunks        # every rank alike
+        else:
+            os.environ.pop("KCCOT_DIST_GATHER_CHUNKS", None)
         step = lambda: kd.sharded_loss_step(shard, SC, epsilon=1.0, L=L, protocol=proto)
+        note(rank, "sharded %s B=%d K=%d: %s" % (tag, B, K, label))
+        err, loss = None, None
         try:
             loss, _ = step()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                loss, _g = step()
-            barrier()
-            el = time.perf_counter() - t0
-            tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            rec["protocols"][proto] = {"ms_fwd_bwd": float(tt) / steps * 1e3, "loss": float(loss),
-                                       "sinkhorn_iters": kd.last_info["nits"].tolist() if "nits" in kd.last_info else None}
-        except Exception as e:           # one protocol failing must not cost the other's record (all ranks fail alike)
-            rec["protocols"][proto] = {"error": repr(e)}
+            torch.cuda.synchronize()
+        except Exception as e:
+            err = repr(e)
+        if not _all_ok(err is None, dev, dist):
+            rec["protocols"][label] = {"error": err or "another rank failed"}
+            continue
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _g = step()
+        barrier()
+        el = _max_over_ranks(time.perf_counter() - t0, dev, dist)
+        # phases: three more steps with an event at every boundary
+        kd.phase_timing(True)
+        for _ in range(3):
+            step()
+        ph = kd.phase_ms()
+        kd.phase_timing(False)
+        n = max(ph.pop("steps", 1), 1)
+        phases = {k: _max_over_ranks(v / n, dev, dist) for k, v in sorted(ph.items())}
+        rec["protocols"][label] = {"ms_fwd_bwd": el / steps * 1e3, "loss": float(loss.detach()), "phases_ms_max_over_ranks": phases,
+                                   "sinkhorn_iters": kd.last_info["nits"].tolist() if "nits" in kd.last_info else None}
+    os.environ.pop("KCCOT_DIST_GATHER_CHUNKS", None)
     ok = {k: v["ms_fwd_bwd"] for k, v in rec["protocols"].items() if "ms_fwd_bwd" in v}
     if ok:
         best = min(ok, key=ok.get)
         rec["ms_fwd_bwd"], rec["protocol"] = ok[best], best
+        rec["samples_per_sec"] = B / (ok[best] * 1e-3)
+    del t, shard
+    torch.cuda.empty_cache()
     return rec
+
+
+def note(rank, msg):
+    """Progress line on stderr (rank 0): a run of several minutes must not look hung to whoever watches the log."""
+    if rank == 0:
+        sys.stderr.write("bench: %s\n" % msg)
+        sys.stderr.flush()
+
+
+def dp_train_children(rank, world, local_rank, backend, timeout_s=200):
+    """Data-parallel train-steps/s (disc step + gen step, kernel_train.py:313-314, GLOBAL-batch loss through
+    kccotgan_amd.dist) in CHILD processes, one per rank, with a rendezvous of their own -- a fault in stock MIOpen must not
+    cost the line, and the children can be given a time limit.  Two runs: `weak` (per-rank batch 64: the configs[1] trainer
+    replicated, global batch 64 N; MIOpen's solver choices come from the shipped find-db) and `strong` (global batch 64,
+    per-rank 64 / N; shapes the find-db does not hold, so MIOpen's fast find mode is used and the line says so)."""
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    out = {}
+    for label, per_rank, find2, off in (("weak_per_rank_batch_64", 64, False, 17), ("strong_global_batch_64", 64 // world, True, 18)):
+        if per_rank < 1 or (64 % world and label.startswith("strong")):
+            continue
+        env = dict(os.environ, MASTER_PORT=str(port + off), KCCOT_TRAIN_DIST_BACKEND=backend)
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+            env.pop(k)        # (TORCHELASTIC_USE_AGENT_STORE would make the children look for the launcher's store on THEIR port)
+        env.pop("KCCOT_OPTIONS", None)
+        env.pop("MIOPEN_FIND_MODE", None)
+        if find2:
+            env["MIOPEN_FIND_MODE"] = "2"
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_train.py"), "--json", "--iters", "3", "--kernel", "none",
+               "--dist", "--batch", str(per_rank)]
+        note(rank, "data-parallel trainer children: %s" % label)
+        t0 = time.perf_counter()
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            so, se = p.communicate(timeout=timeout_s)
+            err = None if p.returncode == 0 else "child exit code %d: %s" % (p.returncode, se.strip()[-300:])
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            so, se = p.communicate()
+            err = "child exceeded %d s" % timeout_s
+        if rank == 0:
+            if err:
+                out[label] = {"value": None, "error": err}
+            else:
+                try:
+                    r = json.loads(so.strip().splitlines()[-1])
+                    out[label] = {"value": r["train_steps_per_sec"], "unit": "train-steps/s (disc step + gen step), all ranks in step",
+                                  "ms_per_train_step": r["ms_per_train_step"], "per_rank_batch": per_rank,
+                                  "global_batch": per_rank * world, "samples_per_sec": per_rank * world * r["train_steps_per_sec"],
+                                  "first_iteration_s": r["first_iteration_s"], "miopen_find_mode": r["find_mode"],
+                                  "loss": r["loss"], "pM": r["pm"], "child_wall_s": time.perf_counter() - t0}
+                except Exception as e:
+                    out[label] = {"value": None, "error": "unreadable child output: %r" % (e,)}
+    return out
 
 
 def main():
@@ -739,10 +834,22 @@ def main():
             if world == 1:
                 cfgs = single_gpu_configs(G, dev)
             else:
+                # EVERY BASELINE config whose batch the ranks divide (not only at the GPU count the config names), plus the
+                # weak-scaling line of the headline shape: per-rank batch 64 -> global batch 64 N at configs[1]'s frames
                 cfgs = {}
-                for name, c in OTHER_CONFIGS.items():
-                    if c[6] == world and c[0] % world == 0:      # every rank takes the same branch: world is global
-                        cfgs[name] = sharded_config(name, rank, world, dev, dist, barrier)
+                rehearsal = backend != "nccl"      # host-staged collectives: fewer steps, and no multi-GB shapes
+                nst = 2 if rehearsal else 5
+                for name, (B, H, T, W, C, L, ngpu) in OTHER_CONFIGS.items():
+                    if rehearsal and 4.0 * B * H * T * W * C > 2e9:
+                        continue
+                    if B % world == 0:                       # every rank takes the same branch: world is global
+                        cfgs[name] = sharded_shape(name, B, H, T, W, C, L, rank, world, dev, dist, barrier, steps=nst)
+                        cfgs[name]["gpus_named_by_config"] = ngpu
+                        cfgs[name]["scaling"] = "strong (the config's global batch on this many GPUs)"
+                wk = sharded_shape("weak", SHAPE["B"] * world, SHAPE["H"], SHAPE["T"], SHAPE["W"], SHAPE["C"], 100, rank, world,
+                                   dev, dist, barrier, steps=nst)
+                wk["scaling"] = "weak (per-rank batch 64 at configs[1]'s frames: the loss of the GLOBAL batch 64 N, what the data-parallel trainer evaluates)"
+                cfgs["configs[1] frames, per-rank batch 64"] = wk
         except Exception as e:
             sys.stderr.write("bench: configs block failed on rank %d: %r\n" % (rank, e))
         if rank == 0 and cfgs:
@@ -753,6 +860,17 @@ def main():
                 out["kernel_smoothing"] = time_smoothing(dev)
             except Exception as e:
                 sys.stderr.write("bench: kernel_smoothing block failed: %r\n" % (e,))
+    if world > 1 and not args.no_train:
+        # the half of BASELINE.json's metric that CAN scale: data-parallel train-steps/s (every rank spawns its child)
+        try:
+            torch.cuda.empty_cache()
+            barrier()
+            r = dp_train_children(rank, world, local_rank, backend)
+            if rank == 0:
+                out["train_steps_per_sec_data_parallel"] = r
+        except Exception as e:
+            sys.stderr.write("bench: data-parallel train block failed on rank %d: %r\n" % (rank, e))
+        barrier()
     if rank == 0 and world == 1:
       try:
         if not args.no_train:

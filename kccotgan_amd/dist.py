@@ -36,6 +36,46 @@ _LMIN = 100
 last_info = {}   # executed Sinkhorn iteration counts of the latest sharded evaluation (device tensor)
 
 
+class _Phases:
+    """Optional per-phase device timing of the sharded step (bench.py's N > 1 blocks: gathers, row block, Sinkhorn, gradient
+    rows -- DESIGN.md section 6's table, measured).  Off by default: `phase_timing(True)` makes the autograd functions below
+    drop a HIP event on the current stream at every phase boundary (a collective issued without async_op makes the current
+    stream wait for it, so the interval that ENDS at a boundary holds the phase's transfers and kernels in stream order);
+    `phase_ms()` synchronises and returns {phase: ms since the previous boundary}, summed over the steps recorded since the
+    last call, plus "steps"."""
+    enabled = False
+    marks = []
+
+    @classmethod
+    def mark(cls, name):
+        if cls.enabled and torch.cuda.is_available():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            cls.marks.append((name, e))
+
+
+def phase_timing(on):
+    _Phases.enabled = bool(on)
+    _Phases.marks = []
+
+
+def phase_ms():
+    torch.cuda.synchronize()
+    out, steps, prev = {}, 0, None
+    for name, e in _Phases.marks:
+        if name == "start":
+            steps += 1
+        elif prev is not None:
+            out[name] = out.get(name, 0.0) + prev.elapsed_time(e)
+        prev = e
+    _Phases.marks = []
+    out["steps"] = steps
+    return out
+
+
+_mark = _Phases.mark
+
+
 class HipOps:
     """The four device operations of the sharded path, through the C-ABI."""
 
@@ -269,11 +309,13 @@ class _KSplitLoss(torch.autograd.Function):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         Bl = real_l.shape[0]
         B = Bl * world
+        _mark("start")
         real_s = all_to_all_slices(real_l, group)
         fake_s = all_to_all_slices(fake_l, group)
         Ks = real_s.shape[1]
         feats = all_gather_cat(torch.stack([h_fake_l, h_real_l, m_real_l, m_fake_l], dim=1), group)
         h_fake, h_real, m_real, m_fake = (feats[:, i].contiguous() for i in range(4))
+        _mark("exchange_inputs")
         T, J = h_fake.shape[1], h_fake.shape[2]
         dev = real_s.device
         # a workspace of its own: the Gram sums must survive between the two calls (the shared scratch is reused)
@@ -288,10 +330,14 @@ class _KSplitLoss(torch.autograd.Function):
         check(lib.kccot_pairwise_cost3_f32(*args, _lib.COST_GRAM_SUMS_ONLY, ptr(C3), ws.data_ptr(), wsb, stream_of(real_s)),
               "pairwise_cost3(gram sums)")
         gsum = ws[off.value:off.value + 8 * cnt.value].view(torch.float64)
+        _mark("cost_gram_sums")
         _all_reduce_sum(gsum, group)
+        _mark("exchange_costs")
         check(lib.kccot_pairwise_cost3_f32(*args, _lib.COST_FROM_GRAM_SUMS, ptr(C3), ws.data_ptr(), wsb, stream_of(real_s)),
               "pairwise_cost3(from gram sums)")
+        _mark("cost_finalize")
         loss, saved = HipOps.divergence_fwd(C3, eps, L)
+        _mark("sinkhorn_fwd")
         last_info["nits"], last_info["nits_executed"] = saved[3][:3], saved[3][3:]
         gan_utils.last_info["compute_sinkhorn_loss"] = saved[3][:3]      # raise_if_solver_aborted() covers the sharded loss too
         ctx.saved_state = (saved, real_s, fake_s, h_fake, h_real, m_real, m_fake)
@@ -304,7 +350,9 @@ class _KSplitLoss(torch.autograd.Function):
         sc, row_begin, Bl, group = ctx.cfg
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("the loss path never differentiates w.r.t. real (kernel_train.py:252,289)")
+        _mark("between_fwd_and_bwd")
         dC3 = HipOps.divergence_bwd(saved, g.reshape(()))
+        _mark("sinkhorn_bwd")
         B, Ks = real_s.shape
         T, J = h_fake.shape[1], h_fake.shape[2]
         # video gradient of ALL samples on this rank's K-slice, then back to the sample-sharded layout
@@ -313,12 +361,15 @@ class _KSplitLoss(torch.autograd.Function):
         check(lib.kccot_pairwise_cost3_bwd_f32(ptr(dC3), ptr(real_s), ptr(fake_s), B, Ks, sc, None, None, None, None, 1, 1,
                                                ptr(dfake_s), None, None, None, None, ws, wsb, stream_of(real_s)),
               "pairwise_cost3_bwd")
+        _mark("gradient")
         dfake = all_to_all_rows(dfake_s, group)
+        _mark("exchange_gradient")
         # feature gradients of this rank's samples (KB-sized products of dC3 with the gathered features)
         dhf, dhr, dmr, dmf = (_lib.empty((Bl, T, J), torch.float32, real_s.device) for _ in range(4))
         check(lib.kccot_pairwise_cost3_bwd_rows_f32(ptr(dC3), ptr(real_s), ptr(fake_s), B, Ks, sc, ptr(h_fake), ptr(h_real),
                                                     ptr(m_real), ptr(m_fake), T, J, row_begin, Bl, None, ptr(dhf), ptr(dhr),
                                                     ptr(dmr), ptr(dmf), None, 0, stream_of(real_s)), "pairwise_cost3_bwd_rows")
+        _mark("gradient")
         return None, dfake, dhf, dhr, dmr, dmf, None, None, None, None
 
 
@@ -400,6 +451,7 @@ class _ShardedLoss(torch.autograd.Function):
     def forward(ctx, real_l, fake_l, h_fake_l, h_real_l, m_real_l, m_fake_l, sc, eps, L, group, ops):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         Bl = real_l.shape[0]
+        _mark("start")
         # B > 64 on the HIP ops: the row block runs on the matrix pipe and needs x.x, e.e, x.e of every sample -- each rank
         # computes its own rows' from its local shard and the 24 bytes per sample are gathered ahead of the videos
         norms = None
@@ -423,6 +475,7 @@ class _ShardedLoss(torch.autograd.Function):
         # the four [Bl,T,J] feature shards travel as one message
         feats = all_gather_cat(torch.stack([h_fake_l, h_real_l, m_real_l, m_fake_l], dim=1), group)
         h_fake, h_real, m_real, m_fake = (feats[:, i].contiguous() for i in range(4))
+        _mark("exchange_inputs")       # (chunked gather: only the small messages -- the video ranges are waited for below)
         if chunked:
             B = Bl * world
             gsum = _lib.empty((int(lib.kccot_pairwise_cost3_rows_gram_sums_count(Bl, B)),), torch.float64, real_l.device)
@@ -435,9 +488,12 @@ class _ShardedLoss(torch.autograd.Function):
                 real.append(r_c)
                 fake.append(f_c)
             blk = ops.rows_gram_from_sums(gsum, B, h_fake, h_real, m_real, m_fake, sc, rank * Bl, Bl, norms)
+            _mark("cost_rows_overlapping_the_gather")
             C3 = all_gather_cat(blk.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()  # [3,B,B]
+            _mark("exchange_costs")
         elif hasattr(ops, "cost3_full") and ops.replicate_costs(real.shape[0], real.shape[1]):
             C3 = ops.cost3_full(real, fake, h_fake, h_real, m_real, m_fake, sc)     # small batch: replicated assembly
+            _mark("cost_replicated")
         else:
             # row blocks of the three cost matrices (gan_utils.py:221-223)
             if norms is not None:                # the Gram row block on the matrix pipe
@@ -448,12 +504,15 @@ class _ShardedLoss(torch.autograd.Function):
                 blk = torch.stack([ops.cost_rows(real_l, fake, h_fake_l, m_real, sc),
                                    ops.cost_rows(real_l, real, h_real_l, m_real, sc),
                                    ops.cost_rows(fake_l, fake, h_fake_l, m_fake, sc)], dim=0)        # [3,Bl,B]
+            _mark("cost_rows")
             C3 = all_gather_cat(blk.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()  # [3,B,B]
+            _mark("exchange_costs")
         if hasattr(ops, "divergence_fwd"):       # solves + combination in one launch
             loss, saved = ops.divergence_fwd(C3, eps, L)
         else:
             cost3, saved = ops.sinkhorn3_fwd(C3, eps, L)
             loss = (2.0 * cost3[0] - cost3[1]) - cost3[2]       # gan_utils.py:225
+        _mark("sinkhorn_fwd")
         if ops is HipOps:
             last_info["nits"], last_info["nits_executed"] = saved[3][:3], saved[3][3:]
             gan_utils.last_info["compute_sinkhorn_loss"] = saved[3][:3]  # raise_if_solver_aborted() covers the sharded loss too
@@ -468,11 +527,13 @@ class _ShardedLoss(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("the loss path never differentiates w.r.t. real (kernel_train.py:252,289)")
         g = g.reshape(())
+        _mark("between_fwd_and_bwd")
         if hasattr(ops, "divergence_bwd"):
             dC3 = ops.divergence_bwd(saved, g)
         else:
             gcost3 = torch.stack([2.0 * g, -g, -g])             # d(2 xy - xx - yy)
             dC3 = ops.sinkhorn3_bwd(saved, gcost3)
+        _mark("sinkhorn_bwd")
         if isinstance(real, list):       # chunked gather: the video gradient is separable in the columns, range by range
             parts = [ops.cost3_bwd_rows(dC3, r_c, f_c, h_fake, h_real, m_real, m_fake, sc, row_begin, Bl)
                      for r_c, f_c in zip(real, fake)]
@@ -480,6 +541,7 @@ class _ShardedLoss(torch.autograd.Function):
             dhf, dhr, dmr, dmf = parts[0][1:]                    # the feature gradients do not depend on the videos
         else:
             dfake, dhf, dhr, dmr, dmf = ops.cost3_bwd_rows(dC3, real, fake, h_fake, h_real, m_real, m_fake, sc, row_begin, Bl)
+        _mark("gradient")
         return None, dfake, dhf, dhr, dmr, dmf, None, None, None, None, None
 
 
