@@ -131,12 +131,36 @@ def time_cost_kernel(t, reps=200):
     return out, K, C3
 
 
-def pmc_child():
-    """`bench.py --pmc-child`: nothing but 20 launches of the dominant cost kernel (KCCOT_COST_PARTIAL_ONLY) at configs[1],
-    for the counter passes of live_pmc_traffic()."""
+def pmc_child(mode="gram"):
+    """`bench.py --pmc-child [gram|smooth]`: the launches the counter passes of live_pmc_traffic() / live_smoothing_traffic()
+    observe and nothing else.  gram: 20 launches of the dominant cost kernel (KCCOT_COST_PARTIAL_ONLY) at configs[1].
+    smooth: KernelSmoothing at the configs[1] shape -- temporal forward, 3-D forward, temporal backward, 3-D backward, five
+    calls each, the four groups separated by a one-element torch fill (the marker the parent splits the dispatch list at)."""
     from kccotgan_amd import _lib
     from kccotgan_amd._lib import lib, ptr, stream_of, workspace, check
     dev = torch.device("cuda", 0)
+    if mode == "smooth":
+        B, H, T, W, C = SHAPE["B"], SHAPE["H"], SHAPE["T"], SHAPE["W"], SHAPE["C"]
+        x = torch.rand(B, H, T, W, C, device=dev); g = torch.randn_like(x)
+        o = torch.empty_like(x); d = torch.empty_like(x); m = torch.empty(1, device=dev)
+        wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        marker = torch.empty(1, device=dev)
+        t_ax, all_ax = _lib.SMOOTH_T, _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W
+        torch.cuda.synchronize()
+        for direction in ("fwd", "bwd"):
+            for axes in (t_ax, all_ax):
+                if direction == "bwd":      # a valid (out, max) pair of this kind for the adjoint
+                    check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 5.0, 3, axes, ptr(o), ptr(m), ws.data_ptr(), wsb, None), "smooth_fwd")
+                marker.fill_(1.0)
+                for _ in range(5):
+                    if direction == "fwd":
+                        check(lib.kccot_smooth_fwd_f32(ptr(x), B, H, T, W, C, 5.0, 3, axes, ptr(o), ptr(m), ws.data_ptr(), wsb, None), "smooth_fwd")
+                    else:
+                        check(lib.kccot_smooth_bwd_f32(ptr(g), ptr(o), ptr(m), B, H, T, W, C, 5.0, 3, axes, ptr(d), ws.data_ptr(), wsb, None), "smooth_bwd")
+                marker.fill_(2.0)
+        torch.cuda.synchronize()
+        return
     _, t = make_inputs(SHAPE["B"], 0, dev)
     B = SHAPE["B"]
     real, fake = t["real"].reshape(B, -1), t["fake"].reshape(B, -1)
@@ -151,28 +175,26 @@ def pmc_child():
     torch.cuda.synchronize()
 
 
-def live_pmc_traffic(kernel_prefix="gram128_partial", timeout_s=120):
-    """HBM-side bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two rocprofv3 passes (--pmc FETCH_SIZE, then
-    --pmc WRITE_SIZE -- one counter per pass, no trace domain besides the kernel trace, as MI355X_MICROARCH.md's HBM section
-    prescribes) over a child process that only launches that kernel; counters in KiB, FETCH_SIZE doubled (gfx950 counts a
-    wide coalesced read at half its bytes).  Returns (bytes, note) or (None, reason): any failure -- no rocprofv3, a
-    profiler already attached to this process, a timeout -- leaves the committed figure of profiles/hbm_traffic.json."""
-    import csv, glob, shutil, signal, subprocess, tempfile
+def pmc_passes(mode, timeout_s=120):
+    """Two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE: one counter per pass, no trace domain besides the kernel
+    trace, as MI355X_MICROARCH.md's HBM section prescribes) over `bench.py --pmc-child <mode>`.  Returns ({counter: [(kernel
+    name, bytes) in dispatch order]}, None) -- counters in KiB -> bytes, no other correction applied here -- or (None, reason):
+    no rocprofv3, a profiler already attached to this process, a timeout (the whole process group is killed: rocprofv3 is a
+    launcher, killing only it would orphan the python child that owns the GPU), a non-zero exit."""
+    import csv, glob, shutil, tempfile
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
     if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
         return None, "this process already runs under a profiler"
-    per = {}
+    out = {}
     tmp = tempfile.mkdtemp(prefix="kccot_pmc_", dir="/tmp")
     try:
         env = dict(os.environ, TMPDIR="/tmp")
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out_dir = os.path.join(tmp, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child"]
-            # own session: on a timeout the WHOLE group dies (rocprofv3 is a launcher -- killing only it would orphan the
-            # python child that owns the GPU, and that child would overlap every timing taken afterwards)
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", mode]
             proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
             try:
                 stdout, _ = proc.communicate(timeout=timeout_s)
@@ -186,23 +208,68 @@ def live_pmc_traffic(kernel_prefix="gram128_partial", timeout_s=120):
             if proc.returncode != 0:
                 tail = " | ".join(stdout.decode(errors="replace").strip().splitlines()[-3:])
                 return None, "rocprofv3 --pmc %s exited with %d: %s" % (counter, proc.returncode, tail[-300:])
-            vals = []
+            rows = []
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") == counter and kernel_prefix in row.get("Kernel_Name", ""):
-                        vals.append(float(row["Counter_Value"]) * 1024.0)
-            if not vals:
-                return None, "no %s rows for %s" % (counter, kernel_prefix)
-            per[counter] = (sum(vals) / len(vals), len(vals))
+                    if row.get("Counter_Name") == counter:
+                        rows.append((int(row.get("Dispatch_Id", len(rows))), row.get("Kernel_Name", ""), float(row["Counter_Value"]) * 1024.0))
+            if not rows:
+                return None, "no %s rows" % counter
+            rows.sort()
+            out[counter] = [(k, v) for _, k, v in rows]
     except Exception as e:            # the bench line must not depend on the profiler
         return None, "counter pass failed: %r" % (e,)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return out, None
+
+
+def live_pmc_traffic(kernel_prefix="gram128_partial"):
+    """HBM-side bytes per launch of the dominant kernel, MEASURED IN THIS RUN (pmc_passes("gram")): FETCH_SIZE doubled (gfx950
+    counts a wide coalesced read at half its bytes).  Returns (bytes, note) or (None, reason): any failure leaves the
+    committed figure of profiles/hbm_traffic.json."""
+    res, why = pmc_passes("gram")
+    if res is None:
+        return None, why
+    per = {}
+    for counter, rows in res.items():
+        vals = [v for k, v in rows if kernel_prefix in k]
+        if not vals:
+            return None, "no %s rows for %s" % (counter, kernel_prefix)
+        per[counter] = (sum(vals) / len(vals), len(vals))
     fetch, write = 2.0 * per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
     return fetch + write, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in two separate passes "
                            "over %d + %d launches of a child process (bench.py --pmc-child), KiB units, FETCH_SIZE x2 (gfx950 "
                            "wide-read correction): fetch %.2f MB + write %.2f MB"
                            % (per["FETCH_SIZE"][1], per["WRITE_SIZE"][1], fetch / 1e6, write / 1e6))
+
+
+def live_smoothing_traffic():
+    """HBM-side bytes per KernelSmoothing CALL at the configs[1] shape, measured in this run (pmc_passes("smooth")): the child
+    runs temporal forward / 3-D forward / temporal backward / 3-D backward, five calls each between one-element torch fills;
+    the dispatch list of each pass is cut at those markers and the kccot kernels between a pair are summed and divided by
+    five.  FETCH_SIZE doubled as for the Gram kernel.  Returns ({"temporal_fwd": bytes, ...}, note) or (None, reason)."""
+    res, why = pmc_passes("smooth")
+    if res is None:
+        return None, why
+    names = ("temporal_fwd", "conv3d_fwd", "temporal_bwd", "conv3d_bwd")
+    tot = {n: 0.0 for n in names}
+    for counter, rows in res.items():
+        groups, cur, opened = [], None, False
+        for k, v in rows:
+            if "FillFunctor" in k:
+                if not opened:
+                    cur, opened = [], True
+                else:
+                    groups.append(cur)
+                    cur, opened = None, False
+            elif opened and "kccot::" in k:
+                cur.append(v)
+        if len(groups) != 4 or not all(groups):
+            return None, "could not split the %s dispatch list at the markers (%d groups)" % (counter, len(groups))
+        for n, g in zip(names, groups):
+            tot[n] += (2.0 if counter == "FETCH_SIZE" else 1.0) * sum(g) / 5.0
+    return tot, "measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE) over bench.py --pmc-child smooth, five calls per kind"
 
 
 def time_sinkhorn(C3, L=100, reps=50):
@@ -596,10 +663,10 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the configs[2..4] block")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-measure roofline.traffic (two rocprofv3 counter passes "
                                                           "over a child process); report the committed figure")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", nargs="?", const="gram", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
-        pmc_child()
+        pmc_child(args.pmc_child)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -821,6 +888,9 @@ def main():
                      "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                      "traffic_committed_pass": committed,
                      "kernel_us": kt["partial"], "cost_stage_us": kt["stage"],
+                     # the same algorithmic bytes over the WHOLE cost stage (Gram partials + fp64 reduction + finalize: three
+                     # launches), for whoever reads the step rather than the kernel
+                     "cost_stage_frac": alg_bytes / (kt["stage"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
                      "timing": "200 launches between two events on the launch stream"})
         out["roofline"] = roof
@@ -858,6 +928,21 @@ def main():
         if rank == 0 and world == 1:
             try:
                 out["kernel_smoothing"] = time_smoothing(dev)
+                # configs[1]: the traffic ratios re-measured in this run (the other shapes keep the committed passes' figures)
+                if not args.no_pmc and "configs[1]" in out["kernel_smoothing"]:
+                    rec = out["kernel_smoothing"]["configs[1]"]
+                    torch.cuda.empty_cache()
+                    live, note = live_smoothing_traffic()
+                    n_el = float(np.prod(rec["shape_BHTWC"]))
+                    if live:
+                        for key in ("temporal", "conv3d"):
+                            for direction, alg in (("fwd", 8.0 * n_el), ("bwd", 12.0 * n_el)):
+                                rec[key][direction + "_traffic_over_algorithmic_committed_pass"] = rec[key].get(direction + "_traffic_over_algorithmic")
+                                rec[key][direction + "_traffic_bytes"] = live["%s_%s" % (key, direction)]
+                                rec[key][direction + "_traffic_over_algorithmic"] = live["%s_%s" % (key, direction)] / alg
+                        rec["traffic_source"] = note
+                    else:
+                        rec["traffic_source"] = "profiles/smooth_traffic.json (committed counter passes) [live counter pass skipped: %s]" % note
             except Exception as e:
                 sys.stderr.write("bench: kernel_smoothing block failed: %r\n" % (e,))
     if world > 1 and not args.no_train:

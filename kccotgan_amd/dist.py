@@ -406,16 +406,19 @@ def gather_chunk_bounds(K, nchunks):
     return bounds
 
 
-def _gather_columns_async(t_l, bounds, group):
+def _gather_columns_async(t_l, bounds, group, force_collective=False):
     """all-gather the column ranges of a [Bl, K] shard as separate collectives: [(work or None, [B, Kc] tensor)] in range
     order.  RCCL: async_op -- the collectives queue up on the communicator's stream and `work.wait()` makes the compute
     stream wait for ONE of them, so what is computed on range c overlaps the transfers of ranges c + 1, ...; gloo (CPU
-    rehearsal with device tensors): staged through the host, no overlap."""
+    rehearsal with device tensors): staged through the host, no overlap.
+    Coverage: the RCCL branch (async_op + work.wait()) has run at world size 1 only (tools/nccl_selftest.py forces the
+    collective there); with two or more ranks it has not executed anywhere yet -- a one-GPU box cannot hold two RCCL ranks,
+    and the two-rank gloo test takes the synchronous branch.  bench.py times it as `gather_chunks` on the first multi-GPU run."""
     world = dist.get_world_size(group)
     out = []
     for a, b in bounds:
         piece = t_l[:, a:b].contiguous()
-        if world == 1:
+        if world == 1 and not force_collective:
             out.append((None, piece))
         elif dist.get_backend(group) == "gloo":
             out.append((None, all_gather_cat(piece, group)))

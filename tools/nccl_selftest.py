@@ -63,6 +63,15 @@ for _ in range(100):
     ks()
 torch.cuda.synchronize()
 print("graphed ksplit step (world 1, nccl calls in place): %.1f us/step" % ((time.perf_counter() - t0) / 100 * 1e6))
+# the chunked video gather's RCCL branch: one async all_gather_into_tensor per column range, waited for range by range
+vid = torch.rand(8, 1024, device=dev)
+bounds = kd.gather_chunk_bounds(1024, 3)
+pieces = kd._gather_columns_async(vid, bounds, None, force_collective=True)
+assert len(pieces) == len(bounds) >= 2 and all(w is not None for w, _ in pieces)
+for (w, full), (a, b) in zip(pieces, bounds):
+    w.wait()
+    assert torch.equal(full, vid[:, a:b])
+torch.cuda.synchronize()
 # raw collectives the contraction-sharded protocol uses, on device tensors
 a2a_in = torch.arange(8, dtype=torch.float32, device=dev)
 a2a_out = torch.empty_like(a2a_in)
