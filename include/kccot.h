@@ -74,6 +74,9 @@ const char* kccot_last_error(void);
  *   cost_tile256              1        0: B % 256 == 0 runs the 128-row tiles of cost_tiled.hip instead of the 256-row ones
  *   cost_blocked              1        0: no 64 x 64-block MFMA path for B % 64 == 0 (the direct VALU kernel serves instead)
  *   apply_m256                1        0: the video gradient of B % 256 == 0 in 64-row blocks instead of 256-row tiles
+ *   apply_one_launch          1        0: the loss's video gradient at B <= 64 as coefficient build + apply (two launches);
+ *                                      1: one launch -- the apply kernel's consumer waves form their coefficient fragments from dC
+ *                                      themselves, the feature gradients run in its spare workgroups
  *   sinkhorn_shortcut         1        0: execute every Sinkhorn iteration; 1: skip iterations EXACTLY once the fp32 state is
  *                                      bit-for-bit periodic (identical results; see kccot_sinkhorn_fwd_f32)
  *   sinkhorn_fused            1        0: kccot_sinkhorn_fused_eligible reports 0 (solve and reverse sweep as two launches)

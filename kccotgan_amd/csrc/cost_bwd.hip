@@ -468,6 +468,191 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3(const unsigned short* __r
     }
 }
 
+// ---- the loss's video gradient at B <= 64 in ONE launch (round 4) ---------------------------------------------------------
+// Until round 4 the backward of compute_sinkhorn_loss at configs[1] was two launches: coeffs_and_causal_grads (builds the
+// coefficient matrix W [B x 2B] from dC and, in further workgroups, the four feature gradients: 6.9 us, nearly all of it
+// launch + memory latency) and apply_coeffs_x3 (dfake = W [X ; Y]: 22.8 us), with a kernel boundary between them.  W is a
+// function of 32 KB of dC alone, and every consumer wave of the apply kernel needs exactly ONE row block of it as MFMA
+// A-fragments -- which it can form itself while its producers are still waiting for the first stack tile from HBM:
+//   lane (m = output row, kh = k-half) loads column m of gxy (its 32 stack rows r < B) and row m / column m of gyy (its 32
+//   rows r >= B) straight from L2, the two lanes of a pair (kh = 0 / 1) together hold every term of the diagonal sum
+//   d[m] = sum_i gxy[i][m] + gyy[m][i] + gyy[i][m]  (one cross-lane add), and the exact three-way split is done in registers.
+// The feature gradients run in 16 spare workgroups (240 column-tile workgroups + 16 = one per CU), one (job, 16-row tile)
+// each, all its 15 k-tiles in sequence.  dfake bits: only d[m]'s summation order differs from build_coeffs (pair of 32-term
+// sums instead of a 256-thread tree); both the fused and the staged loss path take this kernel.
+struct Loss3Apply {
+    const float* gxy;        // [B,B] d loss / d C_xy
+    const float* gyy;        // [B,B] d loss / d C_yy
+    const float* gscale;     // optional upstream scalar (one device float)
+    const float* real;       // [B,K]
+    const float* fake;       // [B,K]
+    float* out;              // dfake [B,K]
+    int B;
+    float sc;
+    int64_t K, ntiles;
+    int nmain;               // workgroups [0, nmain) walk the column tiles; the rest take the feature gradients
+    CausalGradBatch cg;
+    int T, J, gx, gy;        // causal grid: gx k-tiles x gy row tiles x cg.njobs
+};
+
+__global__ __launch_bounds__(512) void apply_coeffs_x3_loss3(Loss3Apply a) {
+    __shared__ __attribute__((aligned(16))) unsigned char zs[2 * AX_BUF];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    float sc = a.sc;
+    if (a.gscale) sc *= a.gscale[0];
+    if ((int)blockIdx.x >= a.nmain) {
+        // ---------------------------------------------------------------- spare workgroups: the four feature gradients
+        if (t >= 256) return;                                 // whole waves; the barriers inside count the live ones
+        const int units = a.gy * a.cg.njobs, nspare = gridDim.x - a.nmain;
+        for (int u = blockIdx.x - a.nmain; u < units; u += nspare)
+            for (int kt = 0; kt < a.gx; ++kt) causal_grads_body(a.cg, a.T, a.J, sc, kt, u % a.gy, u / a.gy);
+        return;
+    }
+    const int B = a.B, rr = 2 * B;                            // stack rows: B of real, B of fake (a multiple of 16, <= 128)
+    const int64_t K = a.K, ntiles = a.ntiles;
+    if (wave < 4) {
+        // ---------------------------------------------------------------- producers (as apply_coeffs_x3)
+        const int c4 = (t & 15) * 4, rp0 = t >> 4;            // column group, first row pair
+        const float* rowp[8];
+        bool rowok[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 2 * (rp0 + 16 * (j >> 1)) + (j & 1);
+            rowok[j] = r < rr;
+            rowp[j] = r < B ? a.real + (int64_t)r * K : a.fake + (int64_t)((r < rr ? r : rr - 1) - B) * K;
+        }
+        float4 v[8];
+        auto load_tile = [&](int64_t tile) {
+            const int64_t col = tile * AM_COLS + c4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = (rowok[j] && col + 4 <= K) ? *reinterpret_cast<const float4*>(rowp[j] + col)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        int64_t tile = blockIdx.x;
+        if (tile < ntiles) load_tile(tile);
+        int buf = 0;
+        for (; tile < ntiles; tile += a.nmain, buf ^= 1) {
+            unsigned char* zb = zs + buf * AX_BUF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * (rp0 + 16 * i);             // even stack row of the pair
+                const float x[4] = {v[2 * i].x, v[2 * i].y, v[2 * i].z, v[2 * i].w};
+                const float y[4] = {v[2 * i + 1].x, v[2 * i + 1].y, v[2 * i + 1].z, v[2 * i + 1].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned ha, ma, la, hb, mb, lb;
+                    split3u(x[c], ha, ma, la);
+                    split3u(y[c], hb, mb, lb);
+                    const int off = (c4 + c) * AX_COLP + r * 2;
+                    *reinterpret_cast<unsigned*>(zb + off) = __builtin_amdgcn_perm(hb, ha, 0x07060302u);
+                    *reinterpret_cast<unsigned*>(zb + AX_PLANE + off) = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
+                    *reinterpret_cast<unsigned*>(zb + 2 * AX_PLANE + off) = __builtin_amdgcn_perm(lb, la, 0x07060302u);
+                }
+            }
+            if (tile + a.nmain < ntiles) load_tile(tile + a.nmain);
+            __syncthreads();
+        }
+        __syncthreads();          // the consumers' closing barrier
+        return;
+    }
+    // -------------------------------------------------------------------- consumers: their W fragments first
+    const int w = wave - 4, mblk = w & 1, cblk = w >> 1;
+    const int nsteps = rr >> 4;
+    abf16x8 Ah[8], Am[8], Al[8];
+    {
+        int m = 32 * mblk + (lane & 31);
+        if (m >= B) m = B - 1;                                // rows past the batch: any valid row (their outputs are not stored)
+        const int kh = lane >> 5;
+        const float two_sc = 2.f * sc;
+        float wv[8][8];
+        float part = 0.f;
+        // every load first (clamped addresses, no control flow): one round trip to L2
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 16 * s + 8 * kh + j;
+                const int rc = r < rr ? r : rr - 1;
+                if (rc < B) {                                 // uniform per (s, j) across the wave only if B % 8 == 0 (host)
+                    wv[s][j] = a.gxy[(int64_t)rc * B + m];
+                } else {
+                    const int q = rc - B;
+                    wv[s][j] = a.gyy[(int64_t)m * B + q] + a.gyy[(int64_t)q * B + m];
+                }
+                if (r >= rr) wv[s][j] = 0.f;
+            }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += wv[s][j];
+        const float d = part + __shfl_xor(part, 32, 64);      // the pair (kh = 0, 1) holds every term of the diagonal sum
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 16 * s + 8 * kh + j;
+                float c = -two_sc * wv[s][j];                 // -2 sc gxy[r][m]  resp.  -2 sc (gyy[m][q] + gyy[q][m])
+                if (r == B + m) c += two_sc * d;
+                split3u(c, hh[j], mm[j], ll[j]);
+            }
+            unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ph[j] = __builtin_amdgcn_perm(hh[2 * j + 1], hh[2 * j], 0x07060302u);
+                pm[j] = __builtin_amdgcn_perm(mm[2 * j + 1], mm[2 * j], 0x07060302u);
+                pl[j] = __builtin_amdgcn_perm(ll[2 * j + 1], ll[2 * j], 0x07060302u);
+            }
+            const uint4 uh = {ph[0], ph[1], ph[2], ph[3]}, um = {pm[0], pm[1], pm[2], pm[3]}, ul = {pl[0], pl[1], pl[2], pl[3]};
+            Ah[s] = *reinterpret_cast<const abf16x8*>(&uh);
+            Am[s] = *reinterpret_cast<const abf16x8*>(&um);
+            Al[s] = *reinterpret_cast<const abf16x8*>(&ul);
+        }
+    }
+    const int boff = (32 * cblk + (lane & 31)) * AX_COLP + 16 * (lane >> 5);
+    int buf = 0;
+    __syncthreads();                                          // the first tile is staged
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += a.nmain, buf ^= 1) {
+        const unsigned char* zb = zs + buf * AX_BUF;
+        const int64_t col = tile * AM_COLS + 32 * cblk + (lane & 31);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s < nsteps) {
+                abf16x8 Bh, Bm, Bl;
+                uint2* ph = reinterpret_cast<uint2*>(&Bh);
+                uint2* pm = reinterpret_cast<uint2*>(&Bm);
+                uint2* pl = reinterpret_cast<uint2*>(&Bl);
+                ph[0] = *reinterpret_cast<const uint2*>(zb + boff + 32 * s);
+                ph[1] = *reinterpret_cast<const uint2*>(zb + boff + 32 * s + 8);
+                pm[0] = *reinterpret_cast<const uint2*>(zb + AX_PLANE + boff + 32 * s);
+                pm[1] = *reinterpret_cast<const uint2*>(zb + AX_PLANE + boff + 32 * s + 8);
+                pl[0] = *reinterpret_cast<const uint2*>(zb + 2 * AX_PLANE + boff + 32 * s);
+                pl[1] = *reinterpret_cast<const uint2*>(zb + 2 * AX_PLANE + boff + 32 * s + 8);
+                // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[s], Bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[s], Bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[s], Bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[s], Bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[s], Bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[s], Bh, acc, 0, 0, 0);
+            }
+        }
+        if (col < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * mblk + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < B) a.out[(int64_t)m * K + col] = acc[r];
+            }
+        }
+        __syncthreads();                                      // this tile is consumed; the next one is staged
+    }
+}
+
 // ---- large batches: 256 output rows per workgroup, the whole stack in one pass -------------------------------
 // apply_coeffs_x3 produces a 64-row output block from a 128-row stack chunk per launch; at B = 512 that is 8 x 8
 // launches, every stack chunk is fetched, split and staged again for each of the 8 row blocks, and the output is
@@ -1084,6 +1269,20 @@ static int cost3_bwd_rows_impl(const float* g3, const float* gscale, const float
     const size_t need = kccot_pairwise_cost3_bwd_workspace_bytes(B, K);
     if (!ws || ws_bytes < need)
         return fail(KCCOT_EWORKSPACE, "pairwise_cost3_bwd: workspace %zu < required %zu", ws_bytes, need);
+    // B <= 64, whole batch, aligned rows: ONE launch (W built by the consumer waves, feature gradients in spare workgroups)
+    if (B <= 64 && B % 8 == 0 && row_begin == 0 && row_count == B && K % 4 == 0 && (uintptr_t)real % 16 == 0 &&
+        (uintptr_t)fake % 16 == 0 && !opt(OPT_APPLY_F32) && opt(OPT_APPLY_ONE_LAUNCH)) {
+        Loss3Apply la{};
+        la.gxy = gxy; la.gyy = gyy; la.gscale = gscale; la.real = real; la.fake = fake; la.out = dfake;
+        la.B = B; la.sc = sc; la.K = K; la.ntiles = (K + AM_COLS - 1) / AM_COLS;
+        la.cg = cg; la.T = T; la.J = J; la.gx = (T * J + 15) / 16; la.gy = (row_count + 15) / 16;
+        const int units = la.gy * cg.njobs;
+        const int nspare = units < 16 ? units : 16;
+        const int64_t cap = 256 - nspare;                    // 101 KB of LDS: one workgroup per CU
+        la.nmain = (int)(la.ntiles < cap ? la.ntiles : cap);
+        hipLaunchKernelGGL(apply_coeffs_x3_loss3, dim3(la.nmain + nspare), dim3(512), 0, st, la);
+        return launch_status("apply_coeffs_x3_loss3");
+    }
     float* Wt = static_cast<float*>(ws);
     unsigned short* W3 = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + align_up((size_t)2 * B * B * sizeof(float), 256));
     if (cg.njobs == 0) {

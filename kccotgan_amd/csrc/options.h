@@ -11,6 +11,7 @@ enum Option {
     OPT_COST_TILE256,            // "cost_tile256"
     OPT_COST_BLOCKED,            // "cost_blocked"
     OPT_APPLY_M256,              // "apply_m256"
+    OPT_APPLY_ONE_LAUNCH,        // "apply_one_launch"
     OPT_SK_SHORTCUT,             // "sinkhorn_shortcut"
     OPT_SK_FUSED,                // "sinkhorn_fused"
     OPT_SK_FUSED_MAX_N,          // "sinkhorn_fused_max_n"
