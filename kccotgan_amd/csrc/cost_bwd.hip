@@ -11,6 +11,7 @@
 // For the loss (gan_utils.py:221-223) fake is y in the xy term and both x and y in the yy term:
 //     dfake_m = 2sc( cs_xy[m] y_m - sum_i gxy[i,m] x_i ) + 2sc( (rs_yy[m]+cs_yy[m]) y_m - sum_r (gyy[m,r]+gyy[r,m]) y_r )
 #include "common.h"
+#include <stdlib.h>
 #include "options.h"
 
 namespace kccot {
@@ -477,9 +478,103 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3(const unsigned short* __r
 //   lane (m = output row, kh = k-half) loads column m of gxy (its 32 stack rows r < B) and row m / column m of gyy (its 32
 //   rows r >= B) straight from L2, the two lanes of a pair (kh = 0 / 1) together hold every term of the diagonal sum
 //   d[m] = sum_i gxy[i][m] + gyy[m][i] + gyy[i][m]  (one cross-lane add), and the exact three-way split is done in registers.
-// The feature gradients run in 16 spare workgroups (240 column-tile workgroups + 16 = one per CU), one (job, 16-row tile)
-// each, all its 15 k-tiles in sequence.  dfake bits: only d[m]'s summation order differs from build_coeffs (pair of 32-term
+// The feature gradients (four small products of dC with the features: 960 wave-sized tasks at configs[1]) are done by the
+// PRODUCER waves right behind their first tile's loads, while the consumers form their fragments.  (Second attempt: after the
+// last tile, in the shadow of the consumers' last MFMAs, coefficient loads straight from L2: 34.2 us against 22.9 + 6.9; third:
+// inside the second tile period: 30.8.)  (First attempt: 16 spare
+// workgroups taking (job, row tile) units, 15 k-tiles each in sequence -- each tile is one memory round trip, ~2.5 us: the
+// spare workgroups ran 37 us past the apply's 23 and the step went from 194 to 231 us.  profiles/r4_ab_apply_one_launch.jsonl)  dfake bits: only d[m]'s summation order differs from build_coeffs (pair of 32-term
 // sums instead of a 256-thread tree); both the fused and the staged loss path take this kernel.
+// causal_grads_body's arithmetic for FOUR rows x 16 columns by ONE wave, no workgroup barrier: quarter `qt` (rows a0 + 4 qt ..
+// + 3) of the 16 x 16 tile (bx, by) of job bz.  LDS private to the wave: per term a 4 x 65 g tile and a 64 x 17 x tile.  Same
+// terms in the same order (term, b, for Bb <= 64) as the 256-thread form: identical bits.
+// In two halves so that the caller can put other loads between them: `load` issues every global load of the task (both
+// terms, unconditionally, at clamped addresses: straight-line code, so the compiler's wait in front of `finish` counts only
+// these loads and leaves younger ones in flight), `finish` does the rest.  Bb <= 64 (one b chunk).
+struct WaveTask {
+    float gv[2][4], xa[2][16], xb[2][16];
+    int k, a0, ta, tk, mode, Ba, Bb;
+    bool use_a, use_b, term[2];
+    float* out;
+};
+
+__device__ __forceinline__ void causal_wave_load(WaveTask& w, const CausalGradBatch& cb, int T, int J, int bx, int by, int bz,
+                                                 int qt, int lane) {
+    const CausalGradJob& jb = cb.job[bz];
+    const int TJ = T * J, KK = (T - 1) * J;
+    w.mode = jb.mode; w.Ba = jb.Ba; w.Bb = jb.Bb; w.out = jb.out;
+    w.a0 = by * 16 + 4 * qt;
+    w.ta = lane >> 4; w.tk = lane & 15;
+    const int Bj = jb.pitch, ab = jb.a_begin;
+    const bool H = jb.mode == CG_H;
+    // this lane's column of the x tile and what it reads of a feature row:  CG_H: row[k+J] - row[k] (k < KK);
+    // CG_M: row[k-J] (k >= J) - row[k] (k < KK)
+    const int k = bx * 16 + w.tk, kc = k < TJ ? k : TJ - 1;
+    const int ka = H ? (kc < KK ? kc + J : kc) : (kc >= J ? kc - J : kc);
+    w.k = k;
+    w.use_a = H ? (k < KK) : (k >= J && k < TJ);
+    w.use_b = k < KK;
+#pragma unroll
+    for (int term = 0; term < 2; ++term) {
+        w.term[term] = jb.g[term] != nullptr;
+        const float* g = jb.g[term] ? jb.g[term] : jb.g[0];           // an absent term: valid addresses, values unused
+        const float* src = jb.src[term] ? jb.src[term] : jb.src[0];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {              // g tile: 4 rows x 64 columns
+            const int e = lane + 64 * m;
+            const int ar = H ? m : (e & 3), bg = H ? lane : (e >> 2);
+            const int ac = (w.a0 + ar < jb.Ba) ? w.a0 + ar : jb.Ba - 1, bc = (bg < jb.Bb) ? bg : jb.Bb - 1;
+            w.gv[term][m] = H ? g[(int64_t)(ab + ac) * Bj + bc] : g[(int64_t)bc * Bj + ab + ac];
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {             // x tile: rows ta + 4 m, this lane's column
+            const int bb = w.ta + 4 * m;
+            const int br = (bb < jb.Bb) ? bb : jb.Bb - 1;
+            const float* row = src + (int64_t)br * TJ;
+            w.xa[term][m] = row[ka];
+            w.xb[term][m] = row[kc];
+        }
+    }
+}
+
+__device__ __forceinline__ void causal_wave_finish(const WaveTask& w, int TJ, float sc, float* lds, int lane, bool store) {
+    const bool H = w.mode == CG_H;
+    float* sg0 = lds;                               // per term: 4 x 65 + 4 pad, then 64 x 17
+#pragma unroll
+    for (int term = 0; term < 2; ++term) {
+        float* sg = sg0 + term * (4 * 65 + 4 + 64 * 17);
+        float* sx = sg + 4 * 65 + 4;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int e = lane + 64 * m;
+            const int ar = H ? m : (e & 3), bg = H ? lane : (e >> 2);
+            sg[ar * 65 + bg] = (w.a0 + ar < w.Ba && bg < w.Bb) ? w.gv[term][m] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int bb = w.ta + 4 * m;
+            const float xh = w.use_a ? w.xa[term][m] - w.xb[term][m] : 0.f;
+            const float xm = (w.use_a ? w.xa[term][m] : 0.f) - (w.use_b ? w.xb[term][m] : 0.f);
+            sx[bb * 17 + w.tk] = (bb < w.Bb) ? (H ? xh : xm) : 0.f;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float tot = 0.f;
+#pragma unroll
+    for (int term = 0; term < 2; ++term) {
+        const float* sg = sg0 + term * (4 * 65 + 4 + 64 * 17);
+        const float* sx = sg + 4 * 65 + 4;
+        if (w.term[term]) {                         // wave-uniform
+#pragma unroll 16
+            for (int bb = 0; bb < 64; ++bb) tot = fmaf(sg[w.ta * 65 + bb], sx[bb * 17 + w.tk], tot);
+        }
+    }
+    const int aa = w.a0 + w.ta;
+    if (store && aa < w.Ba && w.k < TJ) w.out[(int64_t)aa * TJ + w.k] = tot * sc;
+}
+
 struct Loss3Apply {
     const float* gxy;        // [B,B] d loss / d C_xy
     const float* gyy;        // [B,B] d loss / d C_yy
@@ -490,26 +585,27 @@ struct Loss3Apply {
     int B;
     float sc;
     int64_t K, ntiles;
-    int nmain;               // workgroups [0, nmain) walk the column tiles; the rest take the feature gradients
+    int nmain;               // = gridDim.x
     CausalGradBatch cg;
     int T, J, gx, gy;        // causal grid: gx k-tiles x gy row tiles x cg.njobs
 };
 
+constexpr int L3_TASK_FLOATS = 2 * (4 * 65 + 4 + 64 * 17);   // LDS of one wave task: per term a g tile, pad, an x tile
+constexpr int L3_DCP = 65;                                // row pitch of the dC copies (conflict-free row AND column reads)
+
+// B64: the batch is exactly 64 (configs[1]): which stack rows are real / fake is known at compile time; TASKS: feature gradients wanted
+template <bool B64, bool TASKS>
 __global__ __launch_bounds__(512) void apply_coeffs_x3_loss3(Loss3Apply a) {
     __shared__ __attribute__((aligned(16))) unsigned char zs[2 * AX_BUF];
+    __shared__ float task_lds[4 * L3_TASK_FLOATS];        // 43 KB: one task per producer wave
+    float* dcs = reinterpret_cast<float*>(zs + AX_BUF);   // gxy, gyy for the consumers' coefficient build: 33 KB of stage
+                                                          // buffer 1, which the producers first write in their SECOND iteration,
+                                                          // behind the barrier that ends the consumers' build
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     float sc = a.sc;
     if (a.gscale) sc *= a.gscale[0];
-    if ((int)blockIdx.x >= a.nmain) {
-        // ---------------------------------------------------------------- spare workgroups: the four feature gradients
-        if (t >= 256) return;                                 // whole waves; the barriers inside count the live ones
-        const int units = a.gy * a.cg.njobs, nspare = gridDim.x - a.nmain;
-        for (int u = blockIdx.x - a.nmain; u < units; u += nspare)
-            for (int kt = 0; kt < a.gx; ++kt) causal_grads_body(a.cg, a.T, a.J, sc, kt, u % a.gy, u / a.gy);
-        return;
-    }
-    const int B = a.B, rr = 2 * B;                            // stack rows: B of real, B of fake (a multiple of 16, <= 128)
+    const int B = B64 ? 64 : a.B, rr = 2 * B;                 // stack rows: B of real, B of fake (a multiple of 16, <= 128)
     const int64_t K = a.K, ntiles = a.ntiles;
     if (wave < 4) {
         // ---------------------------------------------------------------- producers (as apply_coeffs_x3)
@@ -530,8 +626,33 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_loss3(Loss3Apply a) {
                 v[j] = (rowok[j] && col + 4 <= K) ? *reinterpret_cast<const float4*>(rowp[j] + col)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
         };
+        // The feature gradients: one wave task = four rows x 16 columns of one job (causal_grads_wave); 4 njobs gy gx tasks over
+        // the 4 nmain producer waves of the launch (960 over 960 at configs[1]).
+        // One task per producer wave at configs[1] (960 tasks, 960 waves).  Its loads go out FIRST, the first tile's behind
+        // them: the task's operands are back from L2 after ~1 us and its arithmetic runs inside the ~2.5 us the first tile
+        // needs to arrive from cold HBM (and the consumer waves need to form their fragments) -- nobody waits for it.
+        // (Issued behind the tile's loads instead, the in-order wait made the task start only when the tile had landed:
+        // +3.6 us on the launch.  Inside the second tile period: +3.5.  After the last tile: +11.  16 spare workgroups: +37.)
+        const int total = 4 * a.gx * a.gy * a.cg.njobs;       // TASKS: >= 4
+        const int TJ = a.T * a.J;
+        int task = blockIdx.x * 4 + wave;
+        WaveTask wt;
+        if (TASKS) {
+            const int tc = task < total ? task : total - 1;   // clamped: the loads are unconditional, the store is not
+            const int rest = tc >> 2;
+            causal_wave_load(wt, a.cg, a.T, a.J, rest % a.gx, (rest / a.gx) % a.gy, rest / (a.gx * a.gy), tc & 3, lane);
+        }
         int64_t tile = blockIdx.x;
         if (tile < ntiles) load_tile(tile);
+        __syncthreads();                                      // (the consumers' barrier behind their copy of dC to LDS)
+        if (TASKS) {
+            causal_wave_finish(wt, TJ, sc, task_lds + wave * L3_TASK_FLOATS, lane, task < total);
+            for (task += a.nmain * 4; task < total; task += a.nmain * 4) {  // more tasks than waves (small K): the rest, plainly
+                const int rest = task >> 2;
+                causal_wave_load(wt, a.cg, a.T, a.J, rest % a.gx, (rest / a.gx) % a.gy, rest / (a.gx * a.gy), task & 3, lane);
+                causal_wave_finish(wt, TJ, sc, task_lds + wave * L3_TASK_FLOATS, lane, true);
+            }
+        }
         int buf = 0;
         for (; tile < ntiles; tile += a.nmain, buf ^= 1) {
             unsigned char* zb = zs + buf * AX_BUF;
@@ -568,20 +689,36 @@ __global__ __launch_bounds__(512) void apply_coeffs_x3_loss3(Loss3Apply a) {
         const float two_sc = 2.f * sc;
         float wv[8][8];
         float part = 0.f;
-        // every load first (clamped addresses, no control flow): one round trip to L2
+        // gxy and gyy (2 x 16 KB) into LDS with coalesced 16-byte loads by the 256 consumer threads, rows at pitch 65: the
+        // fragments need row m AND column m of gyy -- straight from L2 the row reads are 64 cache lines per instruction
+        // (2048 line requests per wave on the CU's one vector-memory path: ~4 us)
+        {
+            const int ct = t - 256;
+            const int nvec = B * B / 4;                       // B % 8 == 0 (host)
+            for (int e = ct; e < 2 * nvec; e += 256) {
+                const int which = e >= nvec, f = (e - which * nvec) * 4;
+                const float4 q4 = *reinterpret_cast<const float4*>((which ? a.gyy : a.gxy) + f);
+                float* d0 = dcs + which * 64 * L3_DCP + (f / B) * L3_DCP + (f % B);
+                d0[0] = q4.x; d0[1] = q4.y; d0[2] = q4.z; d0[3] = q4.w;
+            }
+        }
+        __syncthreads();                                      // (the producers pass this one right behind their first loads)
+        const float* lxy = dcs;
+        const float* lyy = dcs + 64 * L3_DCP;
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 16 * s + 8 * kh + j;
-                const int rc = r < rr ? r : rr - 1;
-                if (rc < B) {                                 // uniform per (s, j) across the wave only if B % 8 == 0 (host)
-                    wv[s][j] = a.gxy[(int64_t)rc * B + m];
+                if (B64) {                                    // s < 4: a row of real, else a row of fake -- no selects
+                    if (s < 4) wv[s][j] = lxy[r * L3_DCP + m];
+                    else wv[s][j] = lyy[m * L3_DCP + (r - 64)] + lyy[(r - 64) * L3_DCP + m];
                 } else {
-                    const int q = rc - B;
-                    wv[s][j] = a.gyy[(int64_t)m * B + q] + a.gyy[(int64_t)q * B + m];
+                    const int rc = r < rr ? r : rr - 1;
+                    const int q = rc >= B ? rc - B : 0, rx = rc < B ? rc : 0;
+                    const float vx = lxy[rx * L3_DCP + m], vy = lyy[m * L3_DCP + q] + lyy[q * L3_DCP + m];
+                    wv[s][j] = r >= rr ? 0.f : (rc < B ? vx : vy);
                 }
-                if (r >= rr) wv[s][j] = 0.f;
             }
 #pragma unroll
         for (int s = 0; s < 8; ++s)
@@ -1276,11 +1413,18 @@ static int cost3_bwd_rows_impl(const float* g3, const float* gscale, const float
         la.gxy = gxy; la.gyy = gyy; la.gscale = gscale; la.real = real; la.fake = fake; la.out = dfake;
         la.B = B; la.sc = sc; la.K = K; la.ntiles = (K + AM_COLS - 1) / AM_COLS;
         la.cg = cg; la.T = T; la.J = J; la.gx = (T * J + 15) / 16; la.gy = (row_count + 15) / 16;
-        const int units = la.gy * cg.njobs;
-        const int nspare = units < 16 ? units : 16;
-        const int64_t cap = 256 - nspare;                    // 101 KB of LDS: one workgroup per CU
+        // 101 KB of LDS: one workgroup per CU; 240 (not 256) when that makes the persistent tile loops even (configs[1]: 1920 tiles)
+        const int64_t cap = (la.ntiles % 240 == 0 && la.ntiles % 256 != 0) ? 240 : 256;
         la.nmain = (int)(la.ntiles < cap ? la.ntiles : cap);
-        hipLaunchKernelGGL(apply_coeffs_x3_loss3, dim3(la.nmain + nspare), dim3(512), 0, st, la);
+#ifdef KCCOT_DIAG
+        // timing ablations of the diagnostic twin only (results wrong): KCCOT_L3_ABLATE bit 0: no feature-gradient tasks
+        if (const char* e = getenv("KCCOT_L3_ABLATE")) { if (atoi(e) & 1) la.cg.njobs = 0; }
+#endif
+        const bool tasks = la.cg.njobs > 0;
+        if (B == 64 && tasks) hipLaunchKernelGGL((apply_coeffs_x3_loss3<true, true>), dim3(la.nmain), dim3(512), 0, st, la);
+        else if (B == 64) hipLaunchKernelGGL((apply_coeffs_x3_loss3<true, false>), dim3(la.nmain), dim3(512), 0, st, la);
+        else if (tasks) hipLaunchKernelGGL((apply_coeffs_x3_loss3<false, true>), dim3(la.nmain), dim3(512), 0, st, la);
+        else hipLaunchKernelGGL((apply_coeffs_x3_loss3<false, false>), dim3(la.nmain), dim3(512), 0, st, la);
         return launch_status("apply_coeffs_x3_loss3");
     }
     float* Wt = static_cast<float*>(ws);
