@@ -14,6 +14,17 @@ f = [torch.rand(B, T, 8, device=dev) for _ in range(4)]
 C3 = torch.empty(3, B, B, device=dev)
 ws, wsb = workspace(lib.kccot_pairwise_cost3_workspace_bytes(B, K), real)
 def run(): check(lib.kccot_pairwise_cost3_f32(ptr(real), ptr(fake), B, K, 1 / 15.0, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), T, 8, 0, ptr(C3), ws, wsb, None), "cost3")
+if os.environ.get("KCCOT_PRIME_LIB"):
+    # timing ablations that skip a store (tools/micro/q256_estore_ablate.sh): run ANOTHER build of the library once on the same
+    # workspace first, so that what the ablated build reads back is real data, not the zero pages of a fresh allocation
+    # (zero operands switch less, the chip clocks higher: MI355X_MICROARCH.md, DVFS give-back)
+    import ctypes
+    from kccotgan_amd import _lib as _L
+    prime = ctypes.CDLL(os.environ["KCCOT_PRIME_LIB"])
+    fn = prime.kccot_pairwise_cost3_f32
+    fn.argtypes, fn.restype = _L.lib.kccot_pairwise_cost3_f32.argtypes, ctypes.c_int
+    assert fn(ptr(real), ptr(fake), B, K, 1 / 15.0, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), T, 8, 0, ptr(C3), ws, wsb, None) == 0
+    torch.cuda.synchronize()
 for _ in range(2): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

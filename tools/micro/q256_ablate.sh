@@ -3,11 +3,12 @@
 # COPY of kccotgan_amd/csrc/cost_tile256.hip (the product source carries no hooks) and times the cost stage with each.
 #   bit 0: no global loads      bit 1: no split / LDS writes      bit 2: no workgroup barriers
 #   bit 3: no MFMAs (fragments still read)      bit 4: no LDS fragment reads (MFMAs on stale registers)
+#   bit 5: EPAIR does not store E (round 4: the upper bound of what NOT materialising E could save in the E-writing launch)
 # usage: tools/micro/q256_ablate.sh build   (here, no GPU)   |   tools/micro/q256_ablate.sh run "<B H T W C>"   (GPU box)
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$ROOT"
-VARIANTS="0 1 2 4 16 19"
+VARIANTS=${Q256_VARIANTS:-"0 1 2 4 16 19 32"}
 if [ "$1" = "build" ]; then
     mkdir -p build/abl
     python3 - <<'PY'
@@ -28,6 +29,7 @@ rep('__device__ __forceinline__ void q256_mfma6(qf32x16& acc, const QFrag& a, co
 rep('__device__ __forceinline__ QFrag q256_frag(const unsigned char* zs, int off) {\n    QFrag f;\n',
     '__device__ __forceinline__ QFrag q256_frag(const unsigned char* zs, int off) {\n    QFrag f;\n'
     '    if (Q256_ABL & 16) { asm volatile("" : "=v"(f.h), "=v"(f.m), "=v"(f.l)); return f; }\n')
+rep('                __builtin_amdgcn_raw_buffer_store_b128(', '                if (!(Q256_ABL & 32)) __builtin_amdgcn_raw_buffer_store_b128(')
 s = s.replace('#include "common.h"', '#include "../../kccotgan_amd/csrc/common.h"').replace('#include "cost_internal.h"', '#include "../../kccotgan_amd/csrc/cost_internal.h"').replace('#include "options.h"', '#include "../../kccotgan_amd/csrc/options.h"')
 open("build/abl/cost_tile256_abl.hip", "w").write(s)
 PY
