@@ -54,7 +54,6 @@ struct GramArgs {
     unsigned mask;       // needed sub-tiles, bit sub_index(a,b)
     int64_t K, chunk;
     float* gpart;        // [nchunk][GRAM_SLABS][1024]
-    int deep4;           // producers keep four stages of loads in flight (whole chunks of 4 n stages)
     int nchunk;          // workgroups [0, nchunk) do Gram chunks ...
     int ntiles;          // ... and workgroups nchunk + b (b < gridDim.x - nchunk) the causal tiles b, b + nb, ... < ntiles
     CausalPre cp;
@@ -433,6 +432,8 @@ __device__ __forceinline__ void x3ws_consume(unsigned char* zsA, unsigned char* 
 // replaced by zeros with selects after the wait, so that the compiler sees straight-line load / use code and waits with
 // partial counters (vmcnt(8..15): only the OLDER set has to have landed).  With predicated loads (ld4) it falls back to
 // s_waitcnt vmcnt(0) directly behind the issue and the second set buys nothing (measured: round 2).
+// (FOUR sets in flight -- a ring re-issued four stages ahead, vmcnt(24) in steady state -- measured SLOWER in round 4: kernel
+// 20.9 -> 22.0 us, same box, profiles/r4_ab_gram_deep4.txt: 64 KB per CU in flight already cover the latency, 128 KB queue up.)
 // The loop is peeled so that the number of outstanding loads at every wait is static: prologue 2 sets, steady state
 // (s + 3 < nstage) re-issues both, the last 2 or 3 stages drain.  Barrier count = nstage + 1, as the consumers'.
 struct DeepSet { float4 x[8]; };
@@ -511,49 +512,10 @@ __device__ __forceinline__ void x3ws_produce_deep_impl(const GramArgs& ga, unsig
     __syncthreads();
 }
 
-// FOUR stages of loads in flight (experiment, round 4): whole chunks of 4 n stages, n >= 2, full row blocks.  A ring of four
-// register sets; every trip but the last re-issues each set four stages ahead right after it has been emitted, the last trip
-// drains.  Straight-line per trip, so the waits are partial (vmcnt(24) in steady state).  Barrier count = nstage + 1.
-__device__ __forceinline__ void x3ws_produce_deep4(const GramArgs& ga, unsigned char* zsA, unsigned char* zsB, int t,
-                                                   int64_t kbeg, int nstage) {
-    const int r0 = t >> 4, c4 = (t & 15) * 4;
-    const float* rp[8];
-    bool ok[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        ok[j] = true;
-        rp[j] = (j < 4 ? ga.src1 : ga.src2) + (int64_t)(r0 + 16 * (j & 3)) * ga.K;
-    }
-    const int wbase = r0 * XPITCH + c4 * 2;
-    const bool pd = ga.pair_diff;
-    auto koff = [&](int s) { return kbeg + (int64_t)s * XKT + c4; };
-    DeepSet r[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x3ws_issue(r[j], rp, koff(j));
-    int s = 0;
-    for (; s + 8 <= nstage; s += 4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            x3ws_emit<false>(r[j], ok, true, pd, (j & 1) ? zsB : zsA, wbase);
-            x3ws_issue(r[j], rp, koff(s + j + 4));
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                             // the last four stages: nothing left to issue
-        x3ws_emit<false>(r[j], ok, true, pd, (j & 1) ? zsB : zsA, wbase);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    }
-    __syncthreads();
-}
-
 __device__ __forceinline__ void x3ws_produce_deep(const GramArgs& ga, unsigned char* zsA, unsigned char* zsB, int t,
                                                   int64_t kbeg, int64_t kend, int nstage) {
     // uniform: full row blocks and whole stages need no masking at all
     const bool whole = ga.n1 == 64 && ga.n2 == 64 && kend - kbeg == (int64_t)nstage * XKT;
-    if (whole && nstage >= 8 && (nstage & 3) == 0 && ga.deep4) { x3ws_produce_deep4(ga, zsA, zsB, t, kbeg, nstage); return; }
     if (whole) x3ws_produce_deep_impl<false>(ga, zsA, zsB, t, kbeg, kend, nstage);
     else x3ws_produce_deep_impl<true>(ga, zsA, zsB, t, kbeg, kend, nstage);
 }
@@ -880,7 +842,6 @@ int run_gram(const CostBatch& cb, bool loss3, int64_t K, float sc, int T, int J,
     }
     int ncausal = nslot * cp.nti * cp.ntj;                  // tiles still to be done by gram_reduce's extra workgroups
     ga.nchunk = pl.nchunk; ga.ntiles = 0; ga.cp = cp;
-    ga.deep4 = getenv("KCCOT_GRAM_DEEP4") ? atoi(getenv("KCCOT_GRAM_DEEP4")) : 0;
     int split_mode = (ga.mask == 0x3FFu) ? GRAM_SPLIT_89 : GRAM_SPLIT_NONE;
     const bool compact = ga.mask == 0x3FFu && gram_use_x3();   // gram128_partial_x3ws writes compact records
     gf.compact = compact ? 1 : 0;
