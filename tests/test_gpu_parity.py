@@ -1215,6 +1215,37 @@ def test_one_call_loss_equals_staged_path(G, L):
             assert _same_bits(a.cpu().numpy(), b.cpu().numpy()), (shape, seed, regime)
 
 
+@pytest.mark.parametrize("B,K", [(64, 4096), (40, 2052), (16, 512), (8, 260), (64, 64 * 33 + 4)])
+def test_backward_in_one_launch_equals_the_two_launch_form(G, L, B, K):
+    """Round 4: at B <= 64 (B % 8 == 0) the loss's backward is ONE launch -- the apply kernel's consumer waves form their
+    coefficient fragments from dC, its producer waves compute the four feature gradients (csrc/cost_bwd.hip,
+    apply_coeffs_x3_loss3) -- option "apply_one_launch" = 0 keeps coefficient build + apply.  Same products in the same
+    order except the diagonal sum of W (a pair of 32-term sums instead of a 256-thread tree; it multiplies the sample's own
+    row and then cancels against the other terms): the video gradient agrees to 4e-6 of max|grad| (measured <= 2.2e-6; the
+    oracle tolerance is 2.5e-5), the feature gradients (same terms, same order) bit for bit.  Shapes: full and partial row blocks,
+    K with a ragged last tile, fewer column tiles than CUs (a workgroup then owns several feature-gradient tasks)."""
+    T, J = 6, 8
+    gen = torch.Generator(device=DEV).manual_seed(B * 1000 + K)
+    real = torch.rand((B, K), device=DEV, generator=gen)
+    fake = (real + 0.05 * torch.randn((B, K), device=DEV, generator=gen)).clamp_(0, 1)
+    f = {k: torch.rand((B, T, J), device=DEV, generator=gen) for k in ("h_fake", "m_real", "h_real", "m_fake")}
+    wrt = ["fake", "h_fake", "h_real", "m_real", "m_fake"]
+    res = {}
+    for mode in (1, 0):
+        with L.options(apply_one_launch=mode):
+            tt = dict(f, fake=fake.clone())
+            for k in wrt:
+                tt[k] = tt[k].clone().requires_grad_(True)
+            loss = G.compute_sinkhorn_loss(real, tt["fake"], cases.SC, 0.8, 100, tt["h_fake"], tt["m_real"], tt["h_real"],
+                                           tt["m_fake"], video=False)
+            res[mode] = [loss.detach()] + list(torch.autograd.grad(loss, [tt[k] for k in wrt]))
+    assert torch.equal(res[0][0], res[1][0])
+    scale = float(res[0][1].abs().max())
+    assert float((res[1][1] - res[0][1]).abs().max()) <= 4e-6 * scale
+    for a, b in zip(res[1][2:], res[0][2:]):
+        assert torch.equal(a, b)
+
+
 def test_graphed_loss_is_bit_identical(G, L):
     """A captured hipGraph replays the eager kernels with the eager arguments: same bits; and a replay
     after new inputs were copied into the static buffers follows them."""
