@@ -77,6 +77,9 @@ const char* kccot_last_error(void);
  *   apply_one_launch          1        0: the loss's video gradient at B <= 64 as coefficient build + apply (two launches);
  *                                      1: one launch -- the apply kernel's consumer waves form their coefficient fragments from dC
  *                                      themselves, the feature gradients run in its spare workgroups
+ *   apply_q256                1        0: the video gradient of B % 256 == 0 on 256 x 64 / 128 tiles with the coefficient fragments
+ *                                      streamed from L2; 1: from 512 tiles on, 256 x 256 output tiles with the coefficient panel
+ *                                      staged through LDS (csrc/cost_bwd_q256.hip; bit-identical, 13.7 -> 11.1 ms at configs[4])
  *   sinkhorn_shortcut         1        0: execute every Sinkhorn iteration; 1: skip iterations EXACTLY once the fp32 state is
  *                                      bit-for-bit periodic (identical results; see kccot_sinkhorn_fwd_f32)
  *   sinkhorn_fused            1        0: kccot_sinkhorn_fused_eligible reports 0 (solve and reverse sweep as two launches)

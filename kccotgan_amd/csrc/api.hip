@@ -27,6 +27,7 @@ static const OptDesc g_desc[OPT_COUNT] = {
     {"cost_blocked", 1, 0, 1},
     {"apply_m256", 1, 0, 1},
     {"apply_one_launch", 1, 0, 1},
+    {"apply_q256", 1, 0, 1},
     {"sinkhorn_shortcut", 1, 0, 1},
     {"sinkhorn_fused", 1, 0, 1},
     {"sinkhorn_fused_max_n", 64, 1, 128},

@@ -11,6 +11,7 @@
 // For the loss (gan_utils.py:221-223) fake is y in the xy term and both x and y in the yy term:
 //     dfake_m = 2sc( cs_xy[m] y_m - sum_i gxy[i,m] x_i ) + 2sc( (rs_yy[m]+cs_yy[m]) y_m - sum_r (gyy[m,r]+gyy[r,m]) y_r )
 #include "common.h"
+#include "cost_internal.h"
 #include <stdlib.h>
 #include "options.h"
 
@@ -1307,6 +1308,9 @@ static int launch_apply(const float* Wt, int wpitch, const float* s1, int n1, co
             // tail of the persistent tile loop costs more than the W stream saves (B = 256, K = 368 640: 0.73 vs 0.68 ms;
             // B = 512, K = 2.36 M: 13.2 vs 13.8 ms).
             const int64_t nt128 = (K + AY_COLS - 1) / AY_COLS;
+            // 256 x 256 tiles, W panel through LDS (cost_bwd_q256.hip; option "apply_q256")
+            if (opt(OPT_APPLY_Q256) && apply_q256_applies(Bout, n1, n2, K) && (K + 255) / 256 * (Bout / 256) >= 512)
+                return launch_apply_q256(Wuse, Bt, Rt, s1, n1, s2, n2, Bout, K, out, st);
             if (Bout % AB_MT == 0 && nt128 >= 20 * 256 && n1 % AY_ROWS == 0 && n2 % AY_ROWS == 0) {
                 const unsigned gy = (unsigned)(nt128 < 256 ? nt128 : 256);
                 hipLaunchKernelGGL(apply_coeffs_x3_m256n128, dim3(gy, Bout / AB_MT), dim3(512), 0, st, Wuse, Bt, Rt, s1, n1, s2, n2,

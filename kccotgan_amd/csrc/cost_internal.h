@@ -143,6 +143,10 @@ int run_gram_q256(const CostBatch& cb, int64_t K, float sc, int T, int J, void* 
                   int stage = 0);
 void gram_q256_sums_span(int B, int64_t K, size_t* off, size_t* n);
 bool gram_blocked_eligible(const CostBatch& cb, int64_t K, bool loss3);
+// cost_bwd_q256.hip: the video gradient on 256 x 256 output tiles (W panel through LDS)
+bool apply_q256_applies(int Bout, int n1, int n2, int64_t K);
+int launch_apply_q256(const unsigned short* Wt3use, int Bt, int Rt, const float* s1, int n1, const float* s2, int n2, int Bout,
+                      int64_t K, float* out, hipStream_t st);
 int run_gram_blocked(const CostBatch& cb, int64_t K, float sc, int T, int J, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace kccot

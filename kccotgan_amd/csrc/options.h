@@ -12,6 +12,7 @@ enum Option {
     OPT_COST_BLOCKED,            // "cost_blocked"
     OPT_APPLY_M256,              // "apply_m256"
     OPT_APPLY_ONE_LAUNCH,        // "apply_one_launch"
+    OPT_APPLY_Q256,              // "apply_q256"
     OPT_SK_SHORTCUT,             // "sinkhorn_shortcut"
     OPT_SK_FUSED,                // "sinkhorn_fused"
     OPT_SK_FUSED_MAX_N,          // "sinkhorn_fused_max_n"
