@@ -1478,6 +1478,42 @@ def test_large_batch_video_gradient_forms_agree(G, L, B):
     assert float((grads["tile"] - grads["block"]).abs().max()) <= 1e-6 * scale
 
 
+@pytest.mark.parametrize("B,K", [(256, 131072), (256, 131072 + 36), (512, 65536 + 4)])
+def test_video_gradient_on_256x256_tiles_is_bit_identical(L, B, K):
+    """Round 4, csrc/cost_bwd_q256.hip (option "apply_q256", default 1 from 512 tiles on): 256 x 256 output tiles, the
+    coefficient panel staged through LDS, every wave staging and consuming -- against the 256 x 64 / 128 tile kernels it
+    replaces (option 0).  Same products in the same order per output element: the video gradient agrees BIT FOR BIT, also
+    with a ragged last column tile (K % 256 != 0) and two row tiles (B = 512)."""
+    from kccotgan_amd._lib import lib, ptr, workspace, check
+    gen = torch.Generator(device=DEV).manual_seed(B + K)
+    real = torch.rand((B, K), device=DEV, generator=gen)
+    fake = torch.rand((B, K), device=DEV, generator=gen)
+    g3 = torch.randn((3, B, B), device=DEV, generator=gen) * 1e-3
+    ws, wsb = workspace(lib.kccot_pairwise_cost3_bwd_workspace_bytes(B, K), real)
+    out = {}
+    for mode in (0, 1):
+        with L.options(apply_q256=mode):
+            d = torch.full((B, K), float("nan"), device=DEV)
+            check(lib.kccot_pairwise_cost3_bwd_f32(ptr(g3), ptr(real), ptr(fake), B, K, cases.SC, None, None, None, None, 1, 1,
+                                                   ptr(d), None, None, None, None, ws, wsb, None), "bwd")
+            torch.cuda.synchronize()
+            out[mode] = d
+    assert bool(torch.isfinite(out[1]).all()) and torch.equal(out[0], out[1])
+    # and against the fp64 formula on a few rows (the kernel the option replaces is itself oracle-checked at full size)
+    rows = [0, B // 2 - 1, B - 1]
+    W = torch.zeros((B, 2 * B), dtype=torch.float64, device=DEV)
+    gxy, gyy = g3[0].double(), g3[2].double()
+    W[:, :B] = -2 * cases.SC * gxy.t()
+    W[:, B:] = -2 * cases.SC * (gyy + gyy.t())
+    dsum = gxy.sum(0) + gyy.sum(1) + gyy.sum(0)
+    W[torch.arange(B), B + torch.arange(B)] += 2 * cases.SC * dsum
+    cols = torch.arange(0, K, 257, device=DEV)
+    Z = torch.cat([real[:, cols], fake[:, cols]], 0).double()
+    ref = W[rows] @ Z
+    got = out[1][rows][:, cols].double()
+    assert float((got - ref).abs().max()) <= 2.5e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("B,rows", [(128, 32), (128, 64), (256, 32), (256, 64), (384, 128), (256, 96)])
 def test_video_gradient_of_a_row_block_in_one_launch(G, L, B, rows):
     """kccot_pairwise_cost3_bwd_rows_f32 (the batch-sharded caller's gradient of ITS samples from the replicated dC):
