@@ -142,11 +142,11 @@ __global__ __launch_bounds__(256) void apply_q256(ApplyQ a) {
             }
         };
 
-        qf32x16 acc[16];
+        QAcc acc[16];
 #pragma unroll
         for (int t2 = 0; t2 < 16; ++t2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t2][r] = 0.f;
+            for (int r = 0; r < 16; ++r) QACC(acc[t2], r) = 0.f;
         auto step = [&](const unsigned char* zst) {
             // all four column tiles held (48 fragment registers), every W fragment read ONCE: 24 fragment reads per step
             QFrag bf[4];
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void apply_q256(ApplyQ a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float4 v = {acc[4 * i][r], acc[4 * i + 1][r], acc[4 * i + 2][r], acc[4 * i + 3][r]};
+                    const float4 v = {QACC(acc[4 * i], r), QACC(acc[4 * i + 1], r), QACC(acc[4 * i + 2], r), QACC(acc[4 * i + 3], r)};
                     *reinterpret_cast<float4*>(o + (int64_t)(32 * i + (r & 3) + 8 * (r >> 2)) * K) = v;
                 }
         }

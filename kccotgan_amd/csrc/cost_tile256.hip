@@ -157,11 +157,11 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
     const int aoff = tr0 * 32 * QROWB + lo;
     const int boff = (SAME ? 0 : QP * QROWB) + tc0 * 32 * QROWB + lo;        // a diagonal pair reads its B fragments from the A rows
     const int eoff = ter * 32 * QROWB + lo;
-    qf32x16 acc[NT];
+    QAcc acc[NT];
 #pragma unroll
     for (int t2 = 0; t2 < NT; ++t2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t2][r] = 0.f;
+        for (int r = 0; r < 16; ++r) QACC(acc[t2], r) = 0.f;
     auto step = [&](const unsigned char* zs) {
         if constexpr (SAME) {
             QFrag bf[4];
@@ -253,7 +253,7 @@ __device__ __forceinline__ void q256_body(const Q256Args& a, int pa, int pb, int
         if (SAME && t2 == 9 && wave >= 2) continue;                          // the duplicate of waves 2 and 3
         float* ot = o + (32 * trow) * QP + 32 * tcol;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2)) * QP] = acc[t2][r];
+        for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2)) * QP] = QACC(acc[t2], r);
     }
 }
 

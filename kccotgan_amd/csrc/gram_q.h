@@ -42,7 +42,32 @@ __device__ __forceinline__ QFrag gq_frag(const unsigned char* zs, int off) {
     f.l = *reinterpret_cast<const qbf16x8*>(zs + 2 * PLANE + off);
     return f;
 }
-__device__ __forceinline__ void gq_mfma6(qf32x16& acc, const QFrag& a, const QFrag& b) {   // smallest terms first
+// One 32 x 32 accumulator tile.  (KCCOT_ABLATE_MFMA16: the TIMING-ONLY build of tools/micro/q256_mfma16_ablate.sh -- results are
+// garbage -- keeps it as four 16 x 16 quarter tiles and issues twelve v_mfma_f32_16x16x32_bf16 per fragment pair: the same FLOPs,
+// operand reads and registers; does the shape's higher sustained clock (tools/micro/mfma_shape.hip) survive next to the
+// kernels' LDS and VALU traffic?)
+#ifdef KCCOT_ABLATE_MFMA16
+typedef float qf32x4 __attribute__((ext_vector_type(4)));
+struct QAcc { qf32x4 q[4]; };
+#define QACC(a, r) (a).q[(r) >> 2][(r) & 3]
+__device__ __forceinline__ void gq_mfma6(QAcc& acc, const QFrag& a, const QFrag& b) {
+    acc.q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, acc.q[0], 0, 0, 0);
+    acc.q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, acc.q[1], 0, 0, 0);
+    acc.q[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, acc.q[2], 0, 0, 0);
+    acc.q[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, acc.q[3], 0, 0, 0);
+    acc.q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, acc.q[0], 0, 0, 0);
+    acc.q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, acc.q[1], 0, 0, 0);
+    acc.q[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, acc.q[2], 0, 0, 0);
+    acc.q[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, acc.q[3], 0, 0, 0);
+    acc.q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, acc.q[0], 0, 0, 0);
+    acc.q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, acc.q[1], 0, 0, 0);
+    acc.q[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc.q[2], 0, 0, 0);
+    acc.q[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc.q[3], 0, 0, 0);
+}
+#else
+typedef qf32x16 QAcc;
+#define QACC(a, r) (a)[r]
+__device__ __forceinline__ void gq_mfma6(QAcc& acc, const QFrag& a, const QFrag& b) {   // smallest terms first
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
@@ -50,6 +75,7 @@ __device__ __forceinline__ void gq_mfma6(qf32x16& acc, const QFrag& a, const QFr
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
 }
+#endif
 
 typedef unsigned int qu32x4 __attribute__((ext_vector_type(4)));
 
