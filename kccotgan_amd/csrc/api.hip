@@ -39,6 +39,7 @@ static const OptDesc g_desc[OPT_COUNT] = {
     {"smooth_generic", 0, 0, 1},
     {"smooth_fused_tw", 1, 0, 1},
     {"smooth_bwd_fold", 1, 0, 2},
+    {"smooth_fused3", 1, 0, 2},
 };
 static std::atomic<int> g_val[OPT_COUNT];
 static std::once_flag g_once;

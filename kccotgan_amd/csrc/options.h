@@ -24,6 +24,7 @@ enum Option {
     OPT_SMOOTH_GENERIC,          // "smooth_generic"
     OPT_SMOOTH_FUSED_TW,         // "smooth_fused_tw"
     OPT_SMOOTH_BWD_FOLD,         // "smooth_bwd_fold"
+    OPT_SMOOTH_FUSED3,           // "smooth_fused3"
     OPT_COUNT
 };
 

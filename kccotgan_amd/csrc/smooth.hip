@@ -14,6 +14,8 @@
 #include <math.h>
 #include <float.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <stdio.h>
 #include <stdint.h>
 
 namespace kccot {
@@ -986,6 +988,287 @@ static int launch_tw_plane(const float* in, float* out, int64_t n, int T, int W,
     return launch_status("smooth_tw_plane");
 }
 
+// ---- smooth_fused3: T, W and H stage of the 3-D smoothing in ONE pass (round 4) ---------------------------------------
+// The chain above moves the tensor five times (T+W: read + write, H maxima: read, H write: read + write) and seven times where
+// the (b, h) plane does not fit smooth_tw_plane's LDS budget (configs[4]: T x W*C = 48 x 384).  Here a workgroup owns a column
+// tile (wt columns of W, all of T) of one sample and WALKS along H: every plane piece goes global -> registers (fetched one
+// plane ahead) -> LDS A (rows REFLECTed into a row halo while they are written; the R columns either side come from the
+// neighbouring tile, or REFLECTed at the tensor border, as 4-byte loads) -> T stencil -> LDS B -> W stencil -> a (2R+1)-deep
+// REGISTER window per owned float4 -> H stencil -> out.  Two LDS barriers per plane, no intermediate tensor.  The planes before
+// h0 and behind h1 are the REFLECTed (or neighbouring) ones, loaded and smoothed again: (hseg + 2R) / hseg of the reads, and
+// (wt + 2R) / wt from the column halo -- 1.05 x 1.19 at configs[4], where nothing is segmented along H.
+// The tensor maximum costs one more READ of the input (mode 0: same arithmetic, per-workgroup maxima, no store), the writing
+// pass (mode 1) recomputes s and stores s / max, reducing the maxima itself: three tensor moves + halo instead of five / seven.
+// Same fma order per output as the chain (k = -R .. R ascending on every axis; T, then W, then H): bit-identical results.
+constexpr int F3_NH = 5;            // halo floats a thread may own per plane
+struct Fused3Args {
+    const float* in;
+    float* out;            // null in mode 0
+    float* blockmax;       // mode 0: one maximum per workgroup;  mode 1 with nblk > 0: read
+    const float* mx;       // mode 1 with nblk == 0: the tensor maximum
+    float* mx_out;         // mode 1 with nblk > 0: the tensor maximum is stored here
+    int nblk, mode;        // mode: 0 maxima only, 1 write s / max, 2 write s
+    int H, T, W, wt, ntw, hseg, nseg;
+    Taps tp;
+};
+
+template <int R, int CC, int NI>
+__global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
+    typedef WalkVec<4>::type V4;        // (arrays of HIP's float4 struct stayed in scratch memory; ext-vectors do not)
+    extern __shared__ __attribute__((aligned(16))) float f3lds[];
+    __shared__ float red[16];
+    constexpr int C = CC, NW = 2 * R + 1, RC = R * C, NQ = (RC + 3) / 4, HP = 4 * NQ;
+    const int NT = blockDim.x, tid = threadIdx.x;
+    const int T = a.T, WC = a.W * C, wtc = a.wt * C, Q = wtc >> 2, pitch = wtc + 2 * HP, QA = pitch >> 2;
+    const float inv_qa = 1.0f / (float)QA;
+    float* A = f3lds;                             // (T + 2R) x pitch: the plane piece with row and column halo
+    float* Bf = f3lds + (T + 2 * R) * pitch;      // T x pitch: T-smoothed
+    const int dummy = (2 * T + 2 * R) * pitch;    // four floats behind B: the target of writes a thread has no item for
+    int blk = blockIdx.x;
+    const int tw = blk % a.ntw; blk /= a.ntw;
+    const int seg = blk % a.nseg, b = blk / a.nseg;
+    const int w0 = tw * a.wt, h0 = seg * a.hseg, h1 = min(h0 + a.hseg, a.H);
+    const int64_t P = (int64_t)T * WC;
+    const float* inb = a.in + (int64_t)b * a.H * P + w0 * C;
+    float* outb = a.out ? a.out + (int64_t)b * a.H * P + w0 * C : nullptr;
+
+    // mirror row of row t in the (T + 2R)-row buffer, or -1: rows 1..R also serve -1..-R, rows T-1-R..T-2 serve T..T-1+R
+    auto mirror = [&](int t) { return (t >= 1 && t <= R) ? R - t : ((t >= T - 1 - R && t <= T - 2) ? 2 * (T - 1) - t + R : -1); };
+    // owned float4 items of the interior (fixed for the whole walk)
+    int goff[NI], aoff[NI], amir[NI], boff[NI];
+    bool ok[NI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+        int i = tid + NT * n;
+        ok[n] = i < T * Q;
+        i = ok[n] ? i : T * Q - 1;
+        const int t = i / Q, q = i - t * Q;
+        goff[n] = t * WC + 4 * q;
+        aoff[n] = ok[n] ? (t + R) * pitch + HP + 4 * q : dummy;
+        const int mr = mirror(t);
+        amir[n] = (ok[n] && mr >= 0) ? mr * pitch + HP + 4 * q : dummy;
+        boff[n] = t * pitch + HP + 4 * q;
+    }
+    // owned halo floats: R*C either side of every row
+    int hgo[F3_NH], hao[F3_NH], hmi[F3_NH];
+    const int nhalo = T * 2 * RC;
+#pragma unroll
+    for (int n = 0; n < F3_NH; ++n) {
+        int e = tid + NT * n;
+        const bool hok = e < nhalo;
+        e = hok ? e : nhalo - 1;
+        const int t = e / (2 * RC), j = e - t * 2 * RC;
+        const int side = j >= RC, jj = j - side * RC;
+        const int w = (side ? w0 + a.wt : w0 - R) + jj / C, c = jj % C;
+        hgo[n] = t * WC + (reflect(w, a.W) - w0) * C + c;
+        const int col = side ? HP + wtc + jj : HP - RC + jj;
+        hao[n] = hok ? (t + R) * pitch + col : dummy;
+        const int mr = mirror(t);
+        hmi[n] = (hok && mr >= 0) ? mr * pitch + col : dummy;
+    }
+    float m = 1.f;
+    if (a.mode == 1) {
+        if (a.nblk > 0) {           // the maxima of the preceding mode-0 launch, reduced by every workgroup itself
+            float v = -FLT_MAX;
+            for (int i = tid; i < a.nblk; i += NT) v = fmaxf(v, a.blockmax[i]);
+            m = block_max(v, red);
+            if (blockIdx.x == 0 && tid == 0) a.mx_out[0] = m;
+        } else {
+            m = a.mx[0];
+        }
+    }
+    // 1 / m refined once (what the IEEE division's sequence starts from); the short division is taken for ordinary maxima only
+    float rcp_m = __builtin_amdgcn_rcpf(m);
+    rcp_m = fmaf(fmaf(-m, rcp_m, 1.f), rcp_m, rcp_m);
+    const bool fast_div = fabsf(m) > 0x1p-40f && fabsf(m) < 0x1p40f;
+    V4 win[NI][NW];
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) win[n][j] = V4{0.f, 0.f, 0.f, 0.f};
+    V4 x[NI];
+    float hx[F3_NH];
+    float vmax = -FLT_MAX;
+    const int hlo = h0 - R, hhi = h1 + R;
+#ifdef KCCOT_DIAG
+    const int abl = a.mode >> 8;        // timing ablations of tools/micro/f3_ablate.sh (results wrong)
+    a.mode &= 255;
+#else
+    constexpr int abl = 0;
+#endif
+    {
+        const float* pl = inb + (int64_t)reflect(hlo, a.H) * P;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) x[n] = *reinterpret_cast<const V4*>(pl + goff[n]);
+#pragma unroll
+        for (int n = 0; n < F3_NH; ++n) hx[n] = pl[hgo[n]];
+    }
+    // The walk, unrolled by the depth of the window so that the window's slots are static registers: the plane of trip s of a
+    // round lands in slot s, the H stencil reads the slots in the order s + 1, .., s + NW (mod NW) = oldest .. newest.
+    auto step = [&](auto slot, const int hp) {
+        {
+            constexpr int s = decltype(slot)::value;
+            // ---- registers -> A (the previous plane's T stage finished in front of that plane's second barrier); items a
+            // thread does not own go to a dummy slot behind the buffers: no branches
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                *reinterpret_cast<V4*>(f3lds + aoff[n]) = x[n];
+                *reinterpret_cast<V4*>(f3lds + amir[n]) = x[n];
+            }
+#pragma unroll
+            for (int n = 0; n < F3_NH; ++n) {
+                f3lds[hao[n]] = hx[n];
+                f3lds[hmi[n]] = hx[n];
+            }
+            if (!(abl & 1)) {   // the next plane's piece, in flight across this plane's stencils
+                const float* pl = inb + (int64_t)reflect(min(hp + 1, hhi - 1), a.H) * P;
+#pragma unroll
+                for (int n = 0; n < NI; ++n) x[n] = *reinterpret_cast<const V4*>(pl + goff[n]);
+#pragma unroll
+                for (int n = 0; n < F3_NH; ++n) hx[n] = pl[hgo[n]];
+            }
+            lds_barrier();
+            // ---- T stencil: A -> B over the whole pitch (interior + column halo)
+            if (!(abl & 2)) {
+                // (row = i / QA by a float multiply, exact for these sizes: stepping (t, q) by repeated subtraction as
+                // smooth_tw_plane does costs NT / QA trips per item here, QA being a dozen -- that was 2/3 of the kernel's time)
+                for (int i = tid; i < T * QA; i += NT) {
+                    const int t = (int)(((float)i + 0.5f) * inv_qa), q = i - t * QA;
+                    const float* c0 = A + (t + R) * pitch + 4 * q;
+                    V4 acc = V4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = -R; k <= R; ++k) {
+                        const float w = a.tp.w[k + R];
+                        acc = __builtin_elementwise_fma(V4{w, w, w, w}, *reinterpret_cast<const V4*>(c0 + k * pitch), acc);
+                    }
+                    *reinterpret_cast<V4*>(Bf + t * pitch + 4 * q) = acc;
+                }
+            }
+            lds_barrier();
+            // ---- W stencil: B -> the window's slot s
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                float v[4 * (2 * NQ + 1)];
+#pragma unroll
+                for (int j = 0; j < 2 * NQ + 1; ++j) {
+                    const V4 p = (abl & 4) ? x[n] : *reinterpret_cast<const V4*>(Bf + boff[n] + 4 * (j - NQ));
+                    v[4 * j] = p[0]; v[4 * j + 1] = p[1]; v[4 * j + 2] = p[2]; v[4 * j + 3] = p[3];
+                }
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = -R; k <= R; ++k) acc = fmaf(a.tp.w[k + R], v[HP + j + k * C], acc);
+                    r[j] = acc;
+                }
+                win[n][s] = V4{r[0], r[1], r[2], r[3]};
+            }
+            const int hout = hp - R;
+            if (hout >= h0) {               // else the window is not full yet (uniform)
+                // ---- H stencil over the register window, emit plane hout
+#pragma unroll
+                for (int n = 0; n < NI; ++n) {
+                    V4 acc = V4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const float w = a.tp.w[j];
+                        acc = __builtin_elementwise_fma(V4{w, w, w, w}, win[n][(s + 1 + j) % NW], acc);
+                    }
+                    if (a.mode == 0) {
+                        const float mx4 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+                        vmax = ok[n] ? fmaxf(vmax, mx4) : vmax;
+                    } else {
+                        if (a.mode == 1 && !(abl & 8)) {
+                            if (fast_div) {
+                                // s / m with the loop-invariant divisor: the instruction sequence of the IEEE division (refined
+                                // reciprocal, quotient, two residual corrections) without its scaling steps, which are the
+                                // identity unless the quotient is below 2^-100 (there: within 2^-149 absolute)
+                                const V4 nm = V4{-m, -m, -m, -m}, rr = V4{rcp_m, rcp_m, rcp_m, rcp_m};
+                                V4 q = acc * rr;
+                                q = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, q, acc), rr, q);
+                                q = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, q, acc), rr, q);
+                                acc = q;
+                            } else {
+                                acc[0] = acc[0] / m; acc[1] = acc[1] / m; acc[2] = acc[2] / m; acc[3] = acc[3] / m;
+                            }
+                        }
+                        if (ok[n] && (!(abl & 16) || acc[0] == 123.f)) *reinterpret_cast<V4*>(outb + (int64_t)hout * P + goff[n]) = acc;
+                    }
+                }
+            }
+        }
+    };
+#define KCCOT_F3_STEP(S) if constexpr (S < NW) { if (hp0 + S < hhi) step(std::integral_constant<int, S>{}, hp0 + S); }
+    for (int hp0 = hlo; hp0 < hhi; hp0 += NW) {
+        KCCOT_F3_STEP(0) KCCOT_F3_STEP(1) KCCOT_F3_STEP(2) KCCOT_F3_STEP(3) KCCOT_F3_STEP(4)
+        KCCOT_F3_STEP(5) KCCOT_F3_STEP(6) KCCOT_F3_STEP(7) KCCOT_F3_STEP(8)
+    }
+#undef KCCOT_F3_STEP
+    if (a.mode == 0) {
+        const float bm = block_max(vmax, red);
+        if (tid == 0) a.blockmax[blockIdx.x] = bm;
+    }
+}
+
+struct Fused3Plan { int wt, hseg, ni, nt; size_t lds; int64_t grid; bool ok; };
+
+// tile choice: the cheapest (column halo) x (plane halo) overhead among the power-of-two cuts of W and H that still fills the
+// CUs; NI = float4 items per thread <= 4 at <= 512 threads
+static Fused3Plan fused3_plan(int B, int H, int T, int W, int C, int radius, const void* p0, const void* p1) {
+    Fused3Plan best{};
+    const int mode = opt(OPT_SMOOTH_FUSED3);
+    if (!mode || !(radius == 3 || radius == 4) || !(C == 1 || C == 3)) return best;
+    // where it wins (same-box A/B at the BASELINE frame shapes and batch sizes in between, profiles/r4_ab_smooth_fused3.txt): three
+    // channels from ~20 M elements on (configs[2..4]: -21 / -29 / -29 %); one channel never -- there the chain's T and W stages are
+    // one register-only launch (WALK_RAW_TW) and the tensors are small (configs[1]: 66 against 41 us).  2 = wherever it can run.
+    if (mode == 1 && !(C == 3 && (int64_t)B * H * T * W * C >= 20000000)) return best;
+    if (T < 2 * radius + 2 || H < radius + 2 || W < radius + 2 || ((W * C) & 3) || (((uintptr_t)p0 | (uintptr_t)p1) & 15)) return best;
+    double best_cost = 1e30;
+    int force_wt = 0, force_hs = 0;
+#ifdef KCCOT_DIAG
+    if (const char* e = getenv("KCCOT_F3_PLAN")) sscanf(e, "%d,%d", &force_wt, &force_hs);     // tile experiments (diag twin only)
+#endif
+    for (int wt = W; wt >= 8; wt >>= 1) {
+        if (W % wt || ((wt * C) & 3)) break;
+        if (force_wt && wt != force_wt) continue;
+        const int items = T * (wt * C / 4);
+        int ni = 0, nt = 0;
+        for (int n = 1; n <= (radius == 4 ? 3 : 4) && !ni; ++n) {      // (radius 4 with four items would spill)
+            const int th = ((items + n - 1) / n + 63) / 64 * 64;
+            if (th <= 512) { ni = n; nt = th < 128 ? 128 : th; }
+        }
+        if (!ni || T * 2 * radius * C > F3_NH * nt) continue;
+        const int hp = 4 * ((radius * C + 3) / 4), pitch = wt * C + 2 * hp;
+        const size_t lds = ((size_t)(2 * T + 2 * radius) * pitch + 4) * sizeof(float);
+        if (lds > 64 * 1024) continue;
+        for (int hs = H; hs >= 8; hs = (hs + 1) / 2) {
+            const int64_t grid = (int64_t)B * ((H + hs - 1) / hs) * (W / wt);
+            const double waves = (double)grid * nt / (256.0 * 512.0);      // in units of 512 threads per CU (measured: one such
+                                                                              // round with less halo beats two with more)
+            const double over = (1.0 + 2.0 * radius / wt) * (1.0 + 2.0 * radius / hs);
+            // below one full round the chip idles: price that as if the work were spread over the workgroups there are
+            double cost = over * (waves >= 1.0 ? 1.0 : 1.0 / waves);
+            if (force_hs) cost = hs == force_hs ? 0.0 : 1e29;
+            if (cost < best_cost && grid <= 0x7fffffff) { best_cost = cost; best = Fused3Plan{wt, hs, ni, nt, lds, grid, true}; }
+            if (hs == 8) break;
+        }
+    }
+    return best;
+}
+
+static int launch_fused3(const Fused3Plan& pl, Fused3Args fa, int radius, int C, hipStream_t st) {
+#define KCCOT_F3(RR, CCC, NN) hipLaunchKernelGGL((smooth_fused3<RR, CCC, NN>), dim3((unsigned)pl.grid), dim3(pl.nt), pl.lds, st, fa)
+#define KCCOT_F3_N(RR, CCC)                                                                           \
+    switch (pl.ni) { case 1: KCCOT_F3(RR, CCC, 1); break; case 2: KCCOT_F3(RR, CCC, 2); break;        \
+                     case 3: KCCOT_F3(RR, CCC, 3); break; default: KCCOT_F3(RR, CCC, 4); break; }
+    if (radius == 3) { if (C == 1) { KCCOT_F3_N(3, 1) } else { KCCOT_F3_N(3, 3) } }
+    else { if (C == 1) { KCCOT_F3_N(4, 1) } else { KCCOT_F3_N(4, 3) } }
+#undef KCCOT_F3_N
+#undef KCCOT_F3
+    return launch_status("smooth_fused3");
+}
+
 // rows per workgroup (~16 KB of LDS); 0 = the row does not fit (W * C > 16384)
 static int wrow_rpw(int W, int C) {
     const int64_t WC = (int64_t)W * C;
@@ -1354,6 +1637,37 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
     // division by the all-reduced one -- must evaluate s with the SAME kernels, or the arg-max element comes out as
     // 0.99999994 instead of exactly 1 and the adjoint's `out == 1` tie detection finds nothing: found by the RCCL
     // world-size-1 test, where phase 1 took the per-axis chain and phase 2 the streamed walks)
+    if (r34 && opt(OPT_SMOOTH_STREAM) && axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W)) {
+        const Fused3Plan fp = fused3_plan(B, H, T, W, C, radius, in, out);
+        if (fp.ok) {
+            Fused3Args fa{};
+            fa.in = in; fa.H = H; fa.T = T; fa.W = W; fa.wt = fp.wt; fa.ntw = W / fp.wt; fa.hseg = fp.hseg;
+            fa.nseg = (H + fp.hseg - 1) / fp.hseg; fa.tp = tp;
+            if (!ext) {
+                fa.mode = 0; fa.blockmax = bmax;
+#ifdef KCCOT_DIAG
+                if (const char* e = getenv("KCCOT_F3_ABLATE")) fa.mode |= (atoi(e) & 7) << 8;
+                if (!(getenv("KCCOT_F3_ABLATE") && (atoi(getenv("KCCOT_F3_ABLATE")) & 64)))     // bit 6: writing pass only
+#endif
+                if ((rc = launch_fused3(fp, fa, radius, C, st))) return rc;
+                fa.mode = 0;
+                if (!nodiv && fp.grid <= 4096) {
+                    fa.nblk = (int)fp.grid;       // the writing pass reduces the maxima itself (and stores the maximum)
+                } else {
+                    hipLaunchKernelGGL(reduce_blockmax, dim3(1), dim3(1024), 0, st, (const float*)bmax, fp.grid, max_inout);
+                    if ((rc = launch_status("reduce_blockmax"))) return rc;
+                }
+            }
+            fa.mode = nodiv ? 2 : 1; fa.out = out; fa.mx = max_inout; fa.mx_out = max_inout;
+#ifdef KCCOT_DIAG
+            if (const char* e = getenv("KCCOT_F3_ABLATE")) {
+                fa.mode |= atoi(e) << 8;
+                if (atoi(e) & 32) return 0;         // bit 5: maxima pass only
+            }
+#endif
+            return launch_fused3(fp, fa, radius, C, st);
+        }
+    }
     if (r34 && opt(OPT_SMOOTH_STREAM) && (axes == KCCOT_SMOOTH_T || axes == (KCCOT_SMOOTH_T | KCCOT_SMOOTH_H | KCCOT_SMOOTH_W))) {
         const int64_t WC = (int64_t)W * C;
         const bool three = axes != KCCOT_SMOOTH_T;

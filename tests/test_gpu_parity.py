@@ -1145,6 +1145,67 @@ def test_smoothing_stream_and_legacy_paths_agree(L):
         np.testing.assert_allclose(gs, gl, rtol=0, atol=2e-6 * float(np.abs(gl).max()))
 
 
+@pytest.mark.parametrize("shape,ksize", [((3, 40, 30, 64, 1), 6),      # H cut into segments (halo planes), two column tiles
+                                         ((2, 64, 30, 64, 1), 6),      # configs[1]'s frames
+                                         ((2, 24, 30, 64, 3), 6),      # configs[3]'s frames, C = 3
+                                         ((1, 20, 48, 128, 3), 6),     # configs[4]'s plane: three items per thread, four tiles
+                                         ((2, 12, 12, 16, 1), 8),      # radius 4
+                                         ((2, 11, 14, 24, 3), 8),      # radius 4, C = 3, odd H
+                                         ((70, 9, 8, 8, 1), 6)])       # T = 2 R + 2: every row but two is mirrored; one tile
+def test_fused_3d_smoothing_is_bit_identical_to_the_chain(L, shape, ksize):
+    """Round 4: gaussian_convolution3D as ONE pass per phase (csrc/smooth.hip, smooth_fused3: T and W stencils through LDS, H
+    stencil over a register window while the workgroup walks along H; maxima pass + writing pass = three tensor moves) against
+    the chain of per-axis stages (option "smooth_fused3" = 0: five to seven moves).  Same fma order on every axis: the same
+    bits, normalised and raw (the batch-sharded protocol's two phases), and a maximum of exactly 1.  That the fused kernel is
+    the one that ran is read off the workspace: it never touches the tensor-sized intermediate buffer the chain writes."""
+    from kccotgan_amd._lib import lib, ptr, check
+    from kccotgan_amd import _lib
+    B, H, T, W, C = shape
+    r = ksize // 2
+    axes = _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W
+    v = torch.rand(shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(sum(shape)))
+    n = v.numel()
+    res = {}
+    for fused in (2, 0):         # 2: wherever the kernel can run (1 = only where it is faster: C = 3 from 20 M elements on)
+        with L.options(smooth_fused3=fused):
+            wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+            outs = []
+            for flags in (axes, axes | _lib.SMOOTH_NO_DIVIDE, axes | _lib.SMOOTH_EXTERNAL_MAX):
+                out = torch.full(shape, float("nan"), device=DEV)
+                mx = outs[1].clone() if flags & _lib.SMOOTH_EXTERNAL_MAX else torch.zeros(1, device=DEV)   # phase 2 of the sharded call
+                buf = torch.empty(wsb // 4 + 64, device=DEV)
+                buf[:n] = -7.0                              # the tensor-sized intermediate buffer is the head of the workspace
+                check(lib.kccot_smooth_fwd_f32(ptr(v), B, H, T, W, C, 2.0, r, flags, ptr(out), ptr(mx), buf.data_ptr(), wsb, None),
+                      "smooth_fwd")
+                torch.cuda.synchronize()
+                outs += [out, mx.clone()]
+                touched = bool((buf[:n] != -7.0).any())
+                assert touched == (fused == 0), (shape, fused, "intermediate buffer touched" if touched else "fused kernel did not run")
+            res[fused] = outs
+    for a, b in zip(res[2], res[0]):
+        assert torch.equal(a, b), shape
+    assert float(res[2][0].max()) == 1.0
+    assert torch.equal(res[2][4], res[2][0])        # division by the handed-in maximum = the one-call result
+
+
+def test_fused_3d_smoothing_is_the_default_where_it_was_measured_faster(L):
+    """Option "smooth_fused3" = 1 (default): three channels from 20 M elements on (profiles/r4_ab_smooth_fused3.txt)."""
+    from kccotgan_amd._lib import lib, ptr, check
+    from kccotgan_amd import _lib
+    axes = _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W
+    for shape, fused in (((64, 64, 30, 64, 3), True), ((32, 64, 30, 64, 3), False), ((64, 64, 30, 64, 1), False)):
+        B, H, T, W, C = shape
+        v = torch.rand(shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(B + C))
+        wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+        buf = torch.empty(wsb // 4 + 64, device=DEV)
+        buf[:v.numel()] = -7.0
+        out, mx = torch.empty_like(v), torch.zeros(1, device=DEV)
+        check(lib.kccot_smooth_fwd_f32(ptr(v), B, H, T, W, C, 2.0, 3, axes, ptr(out), ptr(mx), buf.data_ptr(), wsb, None), "smooth_fwd")
+        torch.cuda.synchronize()
+        assert bool((buf[:v.numel()] != -7.0).any()) == (not fused), shape
+        assert float(out.max()) == 1.0
+
+
 # ---------------------------------------------------------------- extension: RBF kernel / MMD (no reference behaviour)
 def test_rbf_mmd_matches_sklearn_definition():
     from sklearn.metrics.pairwise import rbf_kernel
