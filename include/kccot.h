@@ -103,10 +103,11 @@ const char* kccot_last_error(void);
  *                                      them and a sparse fix-up applies them (two tensor reads fewer; data with > 32 arg-max
  *                                      elements -- saturated still regions -- then pays the two-pass chain on top, decided on
  *                                      the device: set 0 for such data); 2: at every size (tests)
- *   smooth_fused3             1        0: the 3-D smoothing as the chain of per-axis stages (five to seven tensor moves); 1: T, W
- *                                      and H stage in ONE pass per call phase (three moves + halo, same bits) where that was
- *                                      measured faster: three channels, >= 20 M elements, radius 3 / 4; 2: wherever it can run
- *                                      (C = 1 or 3; tests)
+ *   smooth_fused3             1        0: the 3-D smoothing as the chain of per-axis stages (five to seven tensor moves forward, seven
+ *                                      backward); 1: T, W and H stage in ONE pass per call phase (three moves + halo; forward: same
+ *                                      bits, backward: to rounding) where that was measured faster: forward three channels and
+ *                                      >= 20 M elements (radius 3 / 4), backward >= 3.5 M elements (radius 3, statistics folded:
+ *                                      smooth_bwd_fold != 0); 2: wherever it can run (C = 1 or 3; tests)
  * ------------------------------------------------------------------------------------------- */
 int kccot_set_option(const char* name, int value);
 int kccot_get_option(const char* name, int* value);

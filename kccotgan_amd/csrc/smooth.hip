@@ -1001,6 +1001,7 @@ static int launch_tw_plane(const float* in, float* out, int64_t n, int T, int W,
 // pass (mode 1) recomputes s and stores s / max, reducing the maxima itself: three tensor moves + halo instead of five / seven.
 // Same fma order per output as the chain (k = -R .. R ascending on every axis; T, then W, then H): bit-identical results.
 constexpr int F3_NH = 5;            // halo floats a thread may own per plane
+constexpr int F3A_NH = 3;           // the same for smooth_fused3_adj (they live in its register window)
 struct Fused3Args {
     const float* in;
     float* out;            // null in mode 0
@@ -1215,14 +1216,18 @@ struct Fused3Plan { int wt, hseg, ni, nt; size_t lds; int64_t grid; bool ok; };
 
 // tile choice: the cheapest (column halo) x (plane halo) overhead among the power-of-two cuts of W and H that still fills the
 // CUs; NI = float4 items per thread <= 4 at <= 512 threads
-static Fused3Plan fused3_plan(int B, int H, int T, int W, int C, int radius, const void* p0, const void* p1) {
+static Fused3Plan fused3_plan(int B, int H, int T, int W, int C, int radius, const void* p0, const void* p1, bool adj = false) {
     Fused3Plan best{};
     const int mode = opt(OPT_SMOOTH_FUSED3);
     if (!mode || !(radius == 3 || radius == 4) || !(C == 1 || C == 3)) return best;
+    if (adj && radius != 3) return best;      // (the nine-deep window of radius 4 does not fit the register file next to the halo's)
     // where it wins (same-box A/B at the BASELINE frame shapes and batch sizes in between, profiles/r4_ab_smooth_fused3.txt): three
     // channels from ~20 M elements on (configs[2..4]: -21 / -29 / -29 %); one channel never -- there the chain's T and W stages are
     // one register-only launch (WALK_RAW_TW) and the tensors are small (configs[1]: 66 against 41 us).  2 = wherever it can run.
-    if (mode == 1 && !(C == 3 && (int64_t)B * H * T * W * C >= 20000000)) return best;
+    // The adjoint (smooth_fused3_adj) replaces seven moves, not five, and wins from ~3.5 M elements on at either channel count
+    // (profiles/r4_ab_smooth_fused3.txt: configs[1] 65.6 -> 54.2 us, configs[2..4] -49 / -47 / -33 %).
+    const int64_t numel = (int64_t)B * H * T * W * C;
+    if (mode == 1 && (adj ? numel < 3500000 : !(C == 3 && numel >= 20000000))) return best;
     if (T < 2 * radius + 2 || H < radius + 2 || W < radius + 2 || ((W * C) & 3) || (((uintptr_t)p0 | (uintptr_t)p1) & 15)) return best;
     double best_cost = 1e30;
     int force_wt = 0, force_hs = 0;
@@ -1234,13 +1239,14 @@ static Fused3Plan fused3_plan(int B, int H, int T, int W, int C, int radius, con
         if (force_wt && wt != force_wt) continue;
         const int items = T * (wt * C / 4);
         int ni = 0, nt = 0;
-        for (int n = 1; n <= (radius == 4 ? 3 : 4) && !ni; ++n) {      // (radius 4 with four items would spill)
+        for (int n = 1; n <= (adj ? 3 : (radius == 4 ? 3 : 4)) && !ni; ++n) {      // (more items would spill)
             const int th = ((items + n - 1) / n + 63) / 64 * 64;
             if (th <= 512) { ni = n; nt = th < 128 ? 128 : th; }
         }
-        if (!ni || T * 2 * radius * C > F3_NH * nt) continue;
+        if (!ni || T * 2 * radius * C > (adj ? F3A_NH : F3_NH) * nt) continue;
         const int hp = 4 * ((radius * C + 3) / 4), pitch = wt * C + 2 * hp;
-        const size_t lds = ((size_t)(2 * T + 2 * radius) * pitch + 4) * sizeof(float);
+        const size_t lds = adj ? ((size_t)T * pitch + (size_t)(T + 4 * radius) * wt * C + 4) * sizeof(float)
+                               : ((size_t)(2 * T + 2 * radius) * pitch + 4) * sizeof(float);
         if (lds > 64 * 1024) continue;
         for (int hs = H; hs >= 8; hs = (hs + 1) / 2) {
             const int64_t grid = (int64_t)B * ((H + hs - 1) / hs) * (W / wt);
@@ -1267,6 +1273,260 @@ static int launch_fused3(const Fused3Plan& pl, Fused3Args fa, int radius, int C,
 #undef KCCOT_F3_N
 #undef KCCOT_F3
     return launch_status("smooth_fused3");
+}
+
+// ---- smooth_fused3_adj: the adjoint of the three stages in ONE pass (round 4) ------------------------------------------------
+// Backward of gaussian_convolution3D where the statistics fold applies (smooth_bwd_fold): the chain reads gout and the forward
+// output, writes H^T, reads it, writes W^T, reads it, writes T^T -- seven tensor moves; here x = gout / max goes straight into a
+// (2R+1)-deep register window while the workgroup walks along H (interior float4 items AND the R columns either side, which the
+// W stage needs H-smoothed), H^T with the border-folded weights of the output plane (uniform per step, planes outside the tensor
+// are zero), then through LDS: W^T over the rows of the plane piece, T^T over its columns, din stored once: read gout, read out
+// (owned planes only, for the two sums of the normalisation's adjoint), write din = three moves + halo.
+// Borders: the adjoint of "REFLECT-pad, then correlate" is "correlate the zero-extended line, then fold the pad back":
+//   din[q] = y[q] + [1 <= q <= R] y[-q] + [L-1-R <= q <= L-2] y[2(L-1)-q],   y[p] = sum_k w[k] x[p+k], x = 0 outside [0, L)
+// W: the tiles at the tensor border add the folded columns in a short pass of their own (R*C floats per row and side);
+// T: the items of rows 1..R and L-1-R..L-2 run the stencil a second time at their mirror row of the zero-extended buffer.
+// Algebraically the chain's position-dependent weights; the sums are associated differently at the folded positions (the
+// chain adds the weights first), so agreement with the chain is to rounding (1e-6 of max|din|), not bit for bit.
+// The statistics (sum of gout * out in fp64, positions of out == 1) are gathered from the owned elements while they stream by,
+// one TieRec per workgroup, as smooth_walk's WALK_ADJS does; maxnorm_bwd_fixup consumes them unchanged.
+struct TieNote8 {                   // TieNote for workgroups of up to 512 threads
+    double part[8]; long long idx[TIE_PER_WG]; int n;
+    __device__ __forceinline__ void clear() { if (threadIdx.x == 0) n = 0; __syncthreads(); }
+    __device__ __forceinline__ void add(long long e) { const int slot = atomicAdd(&n, 1); if (slot < TIE_PER_WG) idx[slot] = e; }
+    __device__ __forceinline__ void store(TieRec* rec, double dot) {
+        dot = wave_sum_d(dot);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = dot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nw = (blockDim.x + 63) >> 6;
+            double d = 0.0;
+            for (int w = 0; w < nw; ++w) d += part[w];
+            rec->dot = d; rec->ties = n; rec->pad = 0;
+            for (int i = 0; i < TIE_PER_WG; ++i) rec->idx[i] = idx[i];
+        }
+    }
+};
+struct Fused3AdjArgs {
+    const float* gout;
+    const float* out_fwd;
+    float* din;
+    const float* mx;
+    TieRec* ties;          // one record per workgroup
+    int H, T, W, wt, ntw, hseg, nseg;
+    Taps tp;
+};
+
+template <int R, int CC, int NI>
+__global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
+    typedef WalkVec<4>::type V4;
+    extern __shared__ __attribute__((aligned(16))) float f3lds[];
+    __shared__ TieNote8 note;
+    constexpr int C = CC, NW = 2 * R + 1, RC = R * C, NQ = (RC + 3) / 4, HP = 4 * NQ, NH = F3A_NH;
+    const int NT = blockDim.x, tid = threadIdx.x;
+    const int T = a.T, WC = a.W * C, wtc = a.wt * C, Q = wtc >> 2, pitch = wtc + 2 * HP;
+    float* A = f3lds;                             // T x pitch: the H^T-smoothed plane piece with its column halo
+    float* Bz = f3lds + T * pitch;                // (T + 4R) x wtc: W^T-smoothed, 2R zero rows above and below
+    const int dummy = T * pitch + (T + 4 * R) * wtc;      // four floats behind: the target of writes a thread has no item for
+    int blk = blockIdx.x;
+    const int tw = blk % a.ntw; blk /= a.ntw;
+    const int seg = blk % a.nseg, b = blk / a.nseg;
+    const int w0 = tw * a.wt, h0 = seg * a.hseg, h1 = min(h0 + a.hseg, a.H);
+    const bool left_edge = w0 == 0, right_edge = w0 + a.wt == a.W;
+    const int64_t P = (int64_t)T * WC;
+    const int64_t base = (int64_t)b * a.H * P + w0 * C;
+    const float* gb = a.gout + base;
+    const float* ob = a.out_fwd + base;
+    float* db = a.din + base;
+    const float m = a.mx[0];
+    float rcp_m = __builtin_amdgcn_rcpf(m);
+    rcp_m = fmaf(fmaf(-m, rcp_m, 1.f), rcp_m, rcp_m);
+    const bool fast_div = fabsf(m) > 0x1p-40f && fabsf(m) < 0x1p40f;
+    for (int i = tid; i < 2 * R * wtc; i += NT) { Bz[i] = 0.f; Bz[(T + 2 * R) * wtc + i] = 0.f; }
+    note.clear();
+
+    int goff[NI], ard[NI], brd[NI], bmir[NI];     // ard / brd: the item's position in A / Bz (writes of items a thread does not
+                                                  // own are redirected to the dummy slot where they happen)
+    bool ok[NI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+        int i = tid + NT * n;
+        ok[n] = i < T * Q;
+        i = ok[n] ? i : T * Q - 1;
+        const int t = i / Q, q = i - t * Q;
+        goff[n] = t * WC + 4 * q;
+        ard[n] = t * pitch + HP + 4 * q;
+        brd[n] = (t + 2 * R) * wtc + 4 * q;
+        const int mt = (t >= 1 && t <= R) ? -t : ((t >= T - 1 - R && t <= T - 2) ? 2 * (T - 1) - t : -4 * R);
+        bmir[n] = (ok[n] && mt > -4 * R) ? (mt + 2 * R) * wtc + 4 * q : -1;
+    }
+    int hgo[NH], hao[NH];
+    float hz[NH];
+    const int nhalo = T * 2 * RC;
+#pragma unroll
+    for (int n = 0; n < NH; ++n) {
+        int e = tid + NT * n;
+        const bool hok = e < nhalo;
+        e = hok ? e : nhalo - 1;
+        const int t = e / (2 * RC), j = e - t * 2 * RC;
+        const int side = j >= RC, jj = j - side * RC;
+        const int w = (side ? w0 + a.wt : w0 - R) + jj / C, c = jj % C;
+        const bool inside = w >= 0 && w < a.W;                  // columns outside the tensor do not exist: zero
+        hgo[n] = t * WC + ((inside ? w : (w < 0 ? 0 : a.W - 1)) - w0) * C + c;
+        hao[n] = hok ? t * pitch + (side ? HP + wtc + jj : HP - RC + jj) : dummy;
+        hz[n] = (hok && inside) ? 1.f : 0.f;
+    }
+    auto div_m = [&](V4 g) -> V4 {           // g / m: the IEEE sequence with the loop-invariant parts hoisted (see smooth_fused3)
+        if (fast_div) {
+            const V4 nm = V4{-m, -m, -m, -m}, rr = V4{rcp_m, rcp_m, rcp_m, rcp_m};
+            V4 q = g * rr;
+            q = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, q, g), rr, q);
+            q = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, q, g), rr, q);
+            return q;
+        }
+        return V4{g[0] / m, g[1] / m, g[2] / m, g[3] / m};
+    };
+    V4 win[NI][NW];
+    float hwin[NH][NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+#pragma unroll
+        for (int n = 0; n < NI; ++n) win[n][j] = V4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NH; ++n) hwin[n][j] = 0.f;
+    }
+    V4 x[NI], of[NI];
+    float hx[NH];
+    double sdot = 0.0;
+    const int hlo = h0 - R, hhi = h1 + R;
+    auto fetch = [&](int hp) {
+        const int hc = min(max(hp, 0), a.H - 1);
+        const float* pg = gb + (int64_t)hc * P;
+        const float* po = ob + (int64_t)hc * P;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) { x[n] = *reinterpret_cast<const V4*>(pg + goff[n]); of[n] = *reinterpret_cast<const V4*>(po + goff[n]); }
+#pragma unroll
+        for (int n = 0; n < NH; ++n) hx[n] = pg[hgo[n]];
+    };
+    fetch(hlo);
+    auto step = [&](auto slot, const int hp) {
+        constexpr int s = decltype(slot)::value;
+        const bool exists = hp >= 0 && hp < a.H, owned = hp >= h0 && hp < h1;       // uniform
+        // ---- x = gout / max into the window's slot s; the two sums from the owned elements
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            const V4 g = x[n];
+            win[n][s] = exists ? div_m(g) : V4{0.f, 0.f, 0.f, 0.f};
+            if (owned && ok[n]) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sdot = fma((double)g[c], (double)of[n][c], sdot);
+                    if (of[n][c] == 1.0f) note.add(base + (int64_t)hp * P + goff[n] + c);
+                }
+            }
+        }
+        {
+            const V4 q = div_m(V4{hx[0], hx[1], hx[2], 0.f});          // NH == 3
+#pragma unroll
+            for (int n = 0; n < NH; ++n) hwin[n][s] = exists ? q[n] * hz[n] : 0.f;
+        }
+        fetch(min(hp + 1, hhi - 1));
+        const int hout = hp - R;
+        if (hout < h0) return;              // window not full yet (uniform)
+        // ---- H^T over the window: the weights of output plane hout (border folds included; a source outside [0, H) is a zero slot)
+        float wh[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            int src; float w;
+            wh[j] = tap<R, true>(a.tp, hout, j - R, a.H, src, w) ? w : 0.f;
+        }
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            V4 acc = V4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NW; ++j) acc = __builtin_elementwise_fma(V4{wh[j], wh[j], wh[j], wh[j]}, win[n][(s + 1 + j) % NW], acc);
+            *reinterpret_cast<V4*>(f3lds + (ok[n] ? ard[n] : dummy)) = acc;
+        }
+#pragma unroll
+        for (int n = 0; n < NH; ++n) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) acc = fmaf(wh[j], hwin[n][(s + 1 + j) % NW], acc);
+            f3lds[hao[n]] = acc;
+        }
+        lds_barrier();
+        // ---- W^T: A -> B (interior columns)
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            float v[4 * (2 * NQ + 1)];
+#pragma unroll
+            for (int j = 0; j < 2 * NQ + 1; ++j) {
+                const V4 p = *reinterpret_cast<const V4*>(A + ard[n] + 4 * (j - NQ));
+                v[4 * j] = p[0]; v[4 * j + 1] = p[1]; v[4 * j + 2] = p[2]; v[4 * j + 3] = p[3];
+            }
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = -R; k <= R; ++k) acc = fmaf(a.tp.w[k + R], v[HP + j + k * C], acc);
+                r[j] = acc;
+            }
+            *reinterpret_cast<V4*>(f3lds + (ok[n] ? T * pitch + brd[n] : dummy)) = V4{r[0], r[1], r[2], r[3]};
+        }
+        lds_barrier();
+        if (left_edge || right_edge) {      // uniform: fold the pad columns back, B[q] += y[-q] resp. y[2(W-1)-q]
+            const int per_side = T * RC, total = per_side * ((left_edge ? 1 : 0) + (right_edge ? 1 : 0));
+            for (int e = tid; e < total; e += NT) {
+                const bool right = !left_edge || e >= per_side;
+                const int e2 = e - ((left_edge && right) ? per_side : 0);
+                const int t = e2 / RC, jc = e2 - t * RC, j = jc / C + 1, c = jc - (j - 1) * C;      // folded column q = j (left) / wt-1-j (right)
+                const float* row = A + t * pitch + HP + c;
+                float sum = 0.f;
+                for (int k = j; k <= R; ++k)        // y[-j] = sum_{k >= j} w[k] x[k-j];  right: the mirror image
+                    sum = fmaf(a.tp.w[k + R], right ? row[(a.wt - 1 - (k - j)) * C] : row[(k - j) * C], sum);
+                float* dst = Bz + (t + 2 * R) * wtc + (right ? a.wt - 1 - j : j) * C + c;
+                *dst += sum;
+            }
+            lds_barrier();
+        }
+        // ---- T^T: B -> din; rows next to the border also take their mirror row of the zero-extended buffer
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            V4 acc = V4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = -R; k <= R; ++k) {
+                const float w = a.tp.w[k + R];
+                acc = __builtin_elementwise_fma(V4{w, w, w, w}, *reinterpret_cast<const V4*>(Bz + brd[n] + k * wtc), acc);
+            }
+            if (bmir[n] >= 0) {
+                V4 acc2 = V4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = -R; k <= R; ++k) {
+                    const float w = a.tp.w[k + R];
+                    acc2 = __builtin_elementwise_fma(V4{w, w, w, w}, *reinterpret_cast<const V4*>(Bz + bmir[n] + k * wtc), acc2);
+                }
+                acc += acc2;
+            }
+            if (ok[n]) *reinterpret_cast<V4*>(db + (int64_t)hout * P + goff[n]) = acc;
+        }
+    };
+#define KCCOT_F3_STEP(S) if constexpr (S < NW) { if (hp0 + S < hhi) step(std::integral_constant<int, S>{}, hp0 + S); }
+    for (int hp0 = hlo; hp0 < hhi; hp0 += NW) {
+        KCCOT_F3_STEP(0) KCCOT_F3_STEP(1) KCCOT_F3_STEP(2) KCCOT_F3_STEP(3) KCCOT_F3_STEP(4)
+        KCCOT_F3_STEP(5) KCCOT_F3_STEP(6) KCCOT_F3_STEP(7) KCCOT_F3_STEP(8)
+    }
+#undef KCCOT_F3_STEP
+    note.store(a.ties + blockIdx.x, sdot);
+}
+
+static int launch_fused3_adj(const Fused3Plan& pl, Fused3AdjArgs fa, int C, hipStream_t st) {
+#define KCCOT_F3A(CCC, NN) hipLaunchKernelGGL((smooth_fused3_adj<3, CCC, NN>), dim3((unsigned)pl.grid), dim3(pl.nt), pl.lds, st, fa)
+#define KCCOT_F3A_N(CCC) switch (pl.ni) { case 1: KCCOT_F3A(CCC, 1); break; case 2: KCCOT_F3A(CCC, 2); break; default: KCCOT_F3A(CCC, 3); break; }
+    if (C == 1) { KCCOT_F3A_N(1) } else { KCCOT_F3A_N(3) }
+#undef KCCOT_F3A_N
+#undef KCCOT_F3A
+    return launch_status("smooth_fused3_adj");
 }
 
 // rows per workgroup (~16 KB of LDS); 0 = the row does not fit (W * C > 16384)
@@ -1827,7 +2087,11 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
     // elements, 33.9 -> 32.8 us at 7.9 M, 350 -> 254 us at 94 M; 3-D 37.8 -> 61.1 us at 2 M, 65.4 -> 79.0 us at 7.9 M,
     // 684 -> 635 us at 94 M.  Option value 1 folds from 4 M (temporal) / 32 M (3-D) elements on, 2 always (tests), 0 never.
     const int fold_opt = opt(OPT_SMOOTH_BWD_FOLD);
-    const bool fold = chain && !stats_in && (fold_opt == 2 || (fold_opt == 1 && n >= (three ? (int64_t)1 << 25 : (int64_t)1 << 22)));
+    // Round 4: with the three adjoint stages in ONE pass (smooth_fused3_adj, which gathers the sums itself) folding pays from
+    // 3.5 M elements on for the 3-D call -- the plan decides.
+    Fused3Plan fpa{};
+    if (chain && three && !stats_in && fold_opt != 0 && ((uintptr_t)out & 15) == 0) fpa = fused3_plan(B, H, T, W, C, radius, gout, din, true);
+    const bool fold = chain && !stats_in && (fold_opt == 2 || fpa.ok || (fold_opt == 1 && n >= (three ? (int64_t)1 << 25 : (int64_t)1 << 22)));
     if (stats_in) {
         res = stats_ext;                                       // the global sums: every kernel below reads res[0], res[1]
     } else if (!fold) {
@@ -1845,7 +2109,7 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
             wa.tp = tp; wa.out_fwd = out; wa.mx = max_in; wa.res = res; wa.ties = recs;
             const int first = fold ? WALK_ADJS : WALK_ADJX;
             const AxisPlan& p1 = three ? ph : pt;               // the stage that reads gout and the forward output
-            const int nrec = (int)((n / (three ? H : T) / p1.vw + 255) / 256);
+            int nrec = (int)((n / (three ? H : T) / p1.vw + 255) / 256);
             // what follows the last stage when the statistics were folded into the first: the sparse fix-up, then the
             // dense chain that only runs when the fix-up found too many arg-max elements
             auto finish = [&]() -> int {
@@ -1875,6 +2139,18 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
                 wa.in = gout; wa.out = din; wa.L = T; wa.S = WC;
                 if ((rc = launch_axis(first, wa, radius, n, pt, st))) return rc;
                 return finish();
+            }
+            {               // all three adjoint stages in one pass (smooth_fused3_adj), the statistics gathered on the way
+                const Fused3Plan& fp = fpa;
+                if (fp.ok) {
+                    Fused3AdjArgs fa{};
+                    fa.gout = gout; fa.out_fwd = out; fa.din = din; fa.mx = max_in; fa.ties = recs;
+                    fa.H = H; fa.T = T; fa.W = W; fa.wt = fp.wt; fa.ntw = W / fp.wt; fa.hseg = fp.hseg;
+                    fa.nseg = (H + fp.hseg - 1) / fp.hseg; fa.tp = tp;
+                    if ((rc = launch_fused3_adj(fp, fa, C, st))) return rc;
+                    nrec = (int)fp.grid;
+                    return finish();
+                }
             }
             // H^T (+ normalisation adjoint): gout -> din;  W^T: din -> tmp;  T^T: tmp -> din
             wa.in = gout; wa.out = twp ? tmp : din; wa.L = H; wa.S = (int64_t)T * WC;

@@ -387,3 +387,66 @@ def test_folded_backward_equals_the_two_pass_backward(shape, ties):
             # the sparse fix-up is deterministic: a second run gives the same bits
             with _lib.options(smooth_bwd_fold=2):
                 assert torch.equal(_bwd(g, o, mx, radius, axes), res[2, 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 40, 30, 64, 1), (2, 24, 30, 64, 3), (1, 20, 48, 128, 3), (70, 9, 8, 8, 1), (2, 11, 14, 24, 3),
+                                   (2, 16, 30, 64, 3)])
+@pytest.mark.parametrize("ties", ["none", "one", "corners", "many"])
+def test_fused_3d_adjoint_equals_the_chain(shape, ties):
+    """Round 4: the backward of gaussian_convolution3D as ONE pass (csrc/smooth.hip, smooth_fused3_adj: x = gout / max into a
+    register window while the workgroup walks along H, H^T with the folded border weights, W^T and T^T through LDS with the
+    pad folded back, the normalisation's two sums gathered on the way) against the chain of per-axis adjoint stages
+    (option "smooth_fused3" = 0).  Same products; at the folded border positions the sums are associated differently
+    (the chain adds the folded weights first): agreement to 2e-6 of max|din|, and to the per-element legacy kernels
+    (smooth_stream = 0) within the folded backward's own tolerance.  Shapes: H cut into segments, two column tiles, one tile
+    with both borders, three items per thread, T = 2 R + 2.  Arg-max sets as in the test above (corners: REFLECT folds several
+    taps onto one neighbour; many: dense fallback).  That the fused kernel ran is read off the workspace's tensor-sized
+    buffer, which only the chain writes."""
+    import torch
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, check, ptr
+    B, H, T, W, C = shape
+    rng = np.random.default_rng(sum(shape) + len(ties))
+    n = int(np.prod(shape))
+    out = rng.random(shape, dtype=np.float32) * 0.98
+    flat = out.reshape(-1)
+    if ties == "one":
+        flat[rng.integers(n)] = 1.0
+    elif ties == "corners":
+        for idx in ((0, 0, 0, 0, 0), (B - 1, H - 1, T - 1, W - 1, C - 1), (0, 1, T - 2, 0, 0), (B - 1, 0, 1, W - 2, C - 1),
+                    (0, H - 1, 0, W - 1, 0), (0, 2, 2, 2, 0), (0, 2, 3, 2, 0)):
+            out[idx] = 1.0
+    elif ties == "many":
+        flat[rng.choice(n, size=45, replace=False)] = 1.0
+    g = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda()
+    o = torch.from_numpy(out).cuda()
+    mx = torch.tensor([1.7], device="cuda")
+    axes = _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W
+    wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+
+    def bwd():
+        din = torch.full(shape, float("nan"), device="cuda")
+        buf = torch.empty(wsb // 4 + 64, device="cuda")
+        buf[:n] = -7.0
+        check(lib.kccot_smooth_bwd_f32(ptr(g), ptr(o), ptr(mx), B, H, T, W, C, 2.1, 3, axes, ptr(din), buf.data_ptr(), wsb, None), "bwd")
+        torch.cuda.synchronize()
+        return din, bool((buf[:n] != -7.0).any())
+
+    with _lib.options(smooth_bwd_fold=2, smooth_fused3=2):
+        fused, touched = bwd()
+        again, _ = bwd()
+    # (many: > 32 arg-max elements; corners where H is one segment: five of them in ONE workgroup's record, > TIE_PER_WG -- both
+    # take the dense fallback behind the fix-up, by design, and that chain writes the buffer)
+    if ties in ("none", "one") or (ties == "corners" and H >= 20):
+        assert not touched, "the fused adjoint did not run"
+    assert torch.equal(fused, again)                    # deterministic
+    with _lib.options(smooth_bwd_fold=2, smooth_fused3=0):
+        chain, touched = bwd()
+    assert touched
+    with _lib.options(smooth_stream=0):
+        legacy, _ = bwd()
+    scale = float(legacy.abs().max())
+    assert bool(torch.isfinite(fused).all())
+    assert float((fused - chain).abs().max()) <= 2e-6 * scale, (shape, ties)
+    assert float((fused - legacy).abs().max()) <= 3e-6 * scale, (shape, ties)
