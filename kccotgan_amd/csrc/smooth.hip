@@ -1013,6 +1013,9 @@ struct Fused3Args {
     Taps tp;
 };
 
+// (Held to 168 registers -- amdgpu_waves_per_eu(3), 13 of them spilled -- a 384-thread workgroup fits a CU twice instead of once:
+// measured 4.61 -> 6.95 ms at configs[4]; the SQ counters say VALU 36 % busy at 1.5 waves per SIMD, so the walk is bound by its
+// LDS round trips and barriers at low occupancy, but spills in the plane loop cost more than the second workgroup hides.)
 template <int R, int CC, int NI>
 __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
     typedef WalkVec<4>::type V4;        // (arrays of HIP's float4 struct stayed in scratch memory; ext-vectors do not)
