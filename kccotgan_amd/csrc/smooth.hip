@@ -1245,6 +1245,10 @@ static Fused3Plan fused3_plan(int B, int H, int T, int W, int C, int radius, con
         for (int n = 1; n <= (adj ? 3 : (radius == 4 ? 3 : 4)) && !ni; ++n) {      // (more items would spill)
             const int th = ((items + n - 1) / n + 63) / 64 * 64;
             if (th <= 512) { ni = n; nt = th < 128 ? 128 : th; }
+            if (adj && ni == 3) nt = 512;       // (two waves per SIMD instead of 1.5, a quarter of the lanes idle: configs[4] 4.67 -> 4.38 ms)
+#ifdef KCCOT_DIAG
+            if (ni && getenv("KCCOT_F3_NT")) nt = atoi(getenv("KCCOT_F3_NT"));     // occupancy experiments (diag twin only)
+#endif
         }
         if (!ni || T * 2 * radius * C > (adj ? F3A_NH : F3_NH) * nt) continue;
         const int hp = 4 * ((radius * C + 3) / 4), pitch = wt * C + 2 * hp;
