@@ -1000,7 +1000,7 @@ static int launch_tw_plane(const float* in, float* out, int64_t n, int T, int W,
 // The tensor maximum costs one more READ of the input (mode 0: same arithmetic, per-workgroup maxima, no store), the writing
 // pass (mode 1) recomputes s and stores s / max, reducing the maxima itself: three tensor moves + halo instead of five / seven.
 // Same fma order per output as the chain (k = -R .. R ascending on every axis; T, then W, then H): bit-identical results.
-constexpr int F3_NH = 5;            // halo floats a thread may own per plane
+constexpr int F3_NH = 3;            // halo floats a thread may own per plane
 constexpr int F3A_NH = 3;           // the same for smooth_fused3_adj (they live in its register window)
 struct Fused3Args {
     const float* in;
@@ -1013,9 +1013,11 @@ struct Fused3Args {
     Taps tp;
 };
 
-// (Held to 168 registers -- amdgpu_waves_per_eu(3), 13 of them spilled -- a 384-thread workgroup fits a CU twice instead of once:
-// measured 4.61 -> 6.95 ms at configs[4]; the SQ counters say VALU 36 % busy at 1.5 waves per SIMD, so the walk is bound by its
-// LDS round trips and barriers at low occupancy, but spills in the plane loop cost more than the second workgroup hides.)
+// Registers decide the occupancy, and the occupancy the speed: the SQ counters of the first version said VALU 36 % busy at 1.5 waves
+// per SIMD (180 registers x 384 threads = ONE workgroup per CU) -- bound by LDS round trips and barriers.  Holding that body to 168
+// registers with amdgpu_waves_per_eu made it SLOWER (4.61 -> 6.95 ms at configs[4]: the spill reloads share vmcnt with the plane
+// prefetch and expose its latency every step); buffer descriptors instead of 64-bit per-lane addresses freed the registers
+// without a spill (158), and two workgroups fit.
 template <int R, int CC, int NI>
 __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
     typedef WalkVec<4>::type V4;        // (arrays of HIP's float4 struct stayed in scratch memory; ext-vectors do not)
@@ -1027,19 +1029,26 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
     const float inv_qa = 1.0f / (float)QA;
     float* A = f3lds;                             // (T + 2R) x pitch: the plane piece with row and column halo
     float* Bf = f3lds + (T + 2 * R) * pitch;      // T x pitch: T-smoothed
-    const int dummy = (2 * T + 2 * R) * pitch;    // four floats behind B: the target of writes a thread has no item for
+    // four floats behind B: the target of writes a thread has no item for (one slot for all: same-address LDS writes do not
+    // serialise -- a slot per thread measured no faster and its 8 KB pushed the configs[2..3] tiles over the LDS budget)
+    const int dummy = (2 * T + 2 * R) * pitch;
     int blk = blockIdx.x;
     const int tw = blk % a.ntw; blk /= a.ntw;
     const int seg = blk % a.nseg, b = blk / a.nseg;
     const int w0 = tw * a.wt, h0 = seg * a.hseg, h1 = min(h0 + a.hseg, a.H);
     const int64_t P = (int64_t)T * WC;
-    const float* inb = a.in + (int64_t)b * a.H * P + w0 * C;
-    float* outb = a.out ? a.out + (int64_t)b * a.H * P + w0 * C : nullptr;
+    // the sample through buffer descriptors: one 32-bit byte offset per lane (+ the plane's in an SGPR) instead of 64-bit
+    // per-lane addresses -- a dozen registers and their adds; offsets are relative to the SAMPLE (the left halo lies in
+    // front of the tile), which the plan keeps below 2 GB
+    typedef unsigned int U4 __attribute__((ext_vector_type(4)));
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (int64_t)b * a.H * P), 0, 0xFFFFFFFFu, 0x00020000);
+    const auto rout = __builtin_amdgcn_make_buffer_rsrc((a.out ? a.out : const_cast<float*>(a.in)) + (int64_t)b * a.H * P, 0, 0xFFFFFFFFu, 0x00020000);
+    const int plane_bytes = (int)(P * 4);
 
     // mirror row of row t in the (T + 2R)-row buffer, or -1: rows 1..R also serve -1..-R, rows T-1-R..T-2 serve T..T-1+R
     auto mirror = [&](int t) { return (t >= 1 && t <= R) ? R - t : ((t >= T - 1 - R && t <= T - 2) ? 2 * (T - 1) - t + R : -1); };
     // owned float4 items of the interior (fixed for the whole walk)
-    int goff[NI], aoff[NI], amir[NI], boff[NI];
+    int goff[NI], amir[NI], boff[NI];         // (the item's slot in A is boff + R * pitch)
     bool ok[NI];
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
@@ -1047,8 +1056,7 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
         ok[n] = i < T * Q;
         i = ok[n] ? i : T * Q - 1;
         const int t = i / Q, q = i - t * Q;
-        goff[n] = t * WC + 4 * q;
-        aoff[n] = ok[n] ? (t + R) * pitch + HP + 4 * q : dummy;
+        goff[n] = (t * WC + w0 * C + 4 * q) * 4;          // bytes within a plane of the sample
         const int mr = mirror(t);
         amir[n] = (ok[n] && mr >= 0) ? mr * pitch + HP + 4 * q : dummy;
         boff[n] = t * pitch + HP + 4 * q;
@@ -1064,7 +1072,7 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
         const int t = e / (2 * RC), j = e - t * 2 * RC;
         const int side = j >= RC, jj = j - side * RC;
         const int w = (side ? w0 + a.wt : w0 - R) + jj / C, c = jj % C;
-        hgo[n] = t * WC + (reflect(w, a.W) - w0) * C + c;
+        hgo[n] = (t * WC + reflect(w, a.W) * C + c) * 4;
         const int col = side ? HP + wtc + jj : HP - RC + jj;
         hao[n] = hok ? (t + R) * pitch + col : dummy;
         const int mr = mirror(t);
@@ -1101,11 +1109,11 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
     constexpr int abl = 0;
 #endif
     {
-        const float* pl = inb + (int64_t)reflect(hlo, a.H) * P;
+        const int so = reflect(hlo, a.H) * plane_bytes;
 #pragma unroll
-        for (int n = 0; n < NI; ++n) x[n] = *reinterpret_cast<const V4*>(pl + goff[n]);
+        for (int n = 0; n < NI; ++n) x[n] = __builtin_bit_cast(V4, (U4)__builtin_amdgcn_raw_buffer_load_b128(rin, goff[n], so, 0));
 #pragma unroll
-        for (int n = 0; n < F3_NH; ++n) hx[n] = pl[hgo[n]];
+        for (int n = 0; n < F3_NH; ++n) hx[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, hgo[n], so, 0));
     }
     // The walk, unrolled by the depth of the window so that the window's slots are static registers: the plane of trip s of a
     // round lands in slot s, the H stencil reads the slots in the order s + 1, .., s + NW (mod NW) = oldest .. newest.
@@ -1116,7 +1124,7 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
             // thread does not own go to a dummy slot behind the buffers: no branches
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
-                *reinterpret_cast<V4*>(f3lds + aoff[n]) = x[n];
+                *reinterpret_cast<V4*>(f3lds + (ok[n] ? boff[n] + R * pitch : dummy)) = x[n];
                 *reinterpret_cast<V4*>(f3lds + amir[n]) = x[n];
             }
 #pragma unroll
@@ -1125,27 +1133,38 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
                 f3lds[hmi[n]] = hx[n];
             }
             if (!(abl & 1)) {   // the next plane's piece, in flight across this plane's stencils
-                const float* pl = inb + (int64_t)reflect(min(hp + 1, hhi - 1), a.H) * P;
+                const int so = reflect(min(hp + 1, hhi - 1), a.H) * plane_bytes;
 #pragma unroll
-                for (int n = 0; n < NI; ++n) x[n] = *reinterpret_cast<const V4*>(pl + goff[n]);
+                for (int n = 0; n < NI; ++n) x[n] = __builtin_bit_cast(V4, (U4)__builtin_amdgcn_raw_buffer_load_b128(rin, goff[n], so, 0));
 #pragma unroll
-                for (int n = 0; n < F3_NH; ++n) hx[n] = pl[hgo[n]];
+                for (int n = 0; n < F3_NH; ++n) hx[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, hgo[n], so, 0));
             }
             lds_barrier();
-            // ---- T stencil: A -> B over the whole pitch (interior + column halo)
+            // ---- T stencil: A -> B over the whole pitch (interior + column halo).  A thread takes a strip of LT rows of one float4
+            // column: LT + 2R rows read once, LT outputs -- 2.5 LDS reads per output instead of 7 (the walk is bound by LDS
+            // bandwidth before VALU issue: ~18 b128 accesses per output float4 against ~60 VALU instructions).  Same fma order.
             if (!(abl & 2)) {
-                // (row = i / QA by a float multiply, exact for these sizes: stepping (t, q) by repeated subtraction as
-                // smooth_tw_plane does costs NT / QA trips per item here, QA being a dozen -- that was 2/3 of the kernel's time)
-                for (int i = tid; i < T * QA; i += NT) {
-                    const int t = (int)(((float)i + 0.5f) * inv_qa), q = i - t * QA;
-                    const float* c0 = A + (t + R) * pitch + 4 * q;
-                    V4 acc = V4{0.f, 0.f, 0.f, 0.f};
+                constexpr int LT = 4;
+                const int nstrip = (T + LT - 1) / LT;
+                for (int i = tid; i < nstrip * QA; i += NT) {
+                    // (strip = i / QA by a float multiply, exact for these sizes: stepping by repeated subtraction as
+                    // smooth_tw_plane does costs NT / QA trips per item here, QA being a dozen -- that was 2/3 of the first version)
+                    const int st = (int)(((float)i + 0.5f) * inv_qa), q = i - st * QA, t0 = st * LT;
+                    const int c0 = t0 * pitch + 4 * q;                      // row t0 - R of the plane = row t0 of A
+                    const int last = (T + 2 * R - 1 - t0) * pitch;          // the strip may overhang the plane: rows clamped
+                    V4 r[LT + 2 * R];
 #pragma unroll
-                    for (int k = -R; k <= R; ++k) {
-                        const float w = a.tp.w[k + R];
-                        acc = __builtin_elementwise_fma(V4{w, w, w, w}, *reinterpret_cast<const V4*>(c0 + k * pitch), acc);
+                    for (int j = 0; j < LT + 2 * R; ++j) r[j] = *reinterpret_cast<const V4*>(A + c0 + min(j * pitch, last));
+#pragma unroll
+                    for (int jo = 0; jo < LT; ++jo) {
+                        V4 acc = V4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k = -R; k <= R; ++k) {
+                            const float w = a.tp.w[k + R];
+                            acc = __builtin_elementwise_fma(V4{w, w, w, w}, r[jo + k + R], acc);
+                        }
+                        *reinterpret_cast<V4*>(f3lds + (t0 + jo < T ? (T + 2 * R + t0 + jo) * pitch + 4 * q : dummy)) = acc;
                     }
-                    *reinterpret_cast<V4*>(Bf + t * pitch + 4 * q) = acc;
                 }
             }
             lds_barrier();
@@ -1197,7 +1216,8 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
                                 acc[0] = acc[0] / m; acc[1] = acc[1] / m; acc[2] = acc[2] / m; acc[3] = acc[3] / m;
                             }
                         }
-                        if (ok[n] && (!(abl & 16) || acc[0] == 123.f)) *reinterpret_cast<V4*>(outb + (int64_t)hout * P + goff[n]) = acc;
+                        if (ok[n] && (!(abl & 16) || acc[0] == 123.f))
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, acc), rout, goff[n], hout * plane_bytes, 0);
                     }
                 }
             }
@@ -1214,6 +1234,7 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
         if (tid == 0) a.blockmax[blockIdx.x] = bm;
     }
 }
+
 
 struct Fused3Plan { int wt, hseg, ni, nt; size_t lds; int64_t grid; bool ok; };
 
@@ -1232,6 +1253,7 @@ static Fused3Plan fused3_plan(int B, int H, int T, int W, int C, int radius, con
     const int64_t numel = (int64_t)B * H * T * W * C;
     if (mode == 1 && (adj ? numel < 3500000 : !(C == 3 && numel >= 20000000))) return best;
     if (T < 2 * radius + 2 || H < radius + 2 || W < radius + 2 || ((W * C) & 3) || (((uintptr_t)p0 | (uintptr_t)p1) & 15)) return best;
+    if ((int64_t)H * T * W * C * 4 >= ((int64_t)1 << 31)) return best;         // byte offsets within a sample are 32-bit
     double best_cost = 1e30;
     int force_wt = 0, force_hs = 0;
 #ifdef KCCOT_DIAG
@@ -1341,10 +1363,12 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
     const int w0 = tw * a.wt, h0 = seg * a.hseg, h1 = min(h0 + a.hseg, a.H);
     const bool left_edge = w0 == 0, right_edge = w0 + a.wt == a.W;
     const int64_t P = (int64_t)T * WC;
-    const int64_t base = (int64_t)b * a.H * P + w0 * C;
-    const float* gb = a.gout + base;
-    const float* ob = a.out_fwd + base;
-    float* db = a.din + base;
+    const int64_t base = (int64_t)b * a.H * P;         // the sample, through buffer descriptors (see smooth_fused3)
+    typedef unsigned int U4 __attribute__((ext_vector_type(4)));
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gout + base), 0, 0xFFFFFFFFu, 0x00020000);
+    const auto ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.out_fwd + base), 0, 0xFFFFFFFFu, 0x00020000);
+    const auto rd = __builtin_amdgcn_make_buffer_rsrc(a.din + base, 0, 0xFFFFFFFFu, 0x00020000);
+    const int plane_bytes = (int)(P * 4);
     const float m = a.mx[0];
     float rcp_m = __builtin_amdgcn_rcpf(m);
     rcp_m = fmaf(fmaf(-m, rcp_m, 1.f), rcp_m, rcp_m);
@@ -1361,7 +1385,7 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
         ok[n] = i < T * Q;
         i = ok[n] ? i : T * Q - 1;
         const int t = i / Q, q = i - t * Q;
-        goff[n] = t * WC + 4 * q;
+        goff[n] = (t * WC + w0 * C + 4 * q) * 4;          // bytes within a plane of the sample
         ard[n] = t * pitch + HP + 4 * q;
         brd[n] = (t + 2 * R) * wtc + 4 * q;
         const int mt = (t >= 1 && t <= R) ? -t : ((t >= T - 1 - R && t <= T - 2) ? 2 * (T - 1) - t : -4 * R);
@@ -1379,7 +1403,7 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
         const int side = j >= RC, jj = j - side * RC;
         const int w = (side ? w0 + a.wt : w0 - R) + jj / C, c = jj % C;
         const bool inside = w >= 0 && w < a.W;                  // columns outside the tensor do not exist: zero
-        hgo[n] = t * WC + ((inside ? w : (w < 0 ? 0 : a.W - 1)) - w0) * C + c;
+        hgo[n] = (t * WC + (inside ? w : (w < 0 ? 0 : a.W - 1)) * C + c) * 4;
         hao[n] = hok ? t * pitch + (side ? HP + wtc + jj : HP - RC + jj) : dummy;
         hz[n] = (hok && inside) ? 1.f : 0.f;
     }
@@ -1408,12 +1432,14 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
     const int hlo = h0 - R, hhi = h1 + R;
     auto fetch = [&](int hp) {
         const int hc = min(max(hp, 0), a.H - 1);
-        const float* pg = gb + (int64_t)hc * P;
-        const float* po = ob + (int64_t)hc * P;
+        const int so = hc * plane_bytes;
 #pragma unroll
-        for (int n = 0; n < NI; ++n) { x[n] = *reinterpret_cast<const V4*>(pg + goff[n]); of[n] = *reinterpret_cast<const V4*>(po + goff[n]); }
+        for (int n = 0; n < NI; ++n) {
+            x[n] = __builtin_bit_cast(V4, (U4)__builtin_amdgcn_raw_buffer_load_b128(rg, goff[n], so, 0));
+            of[n] = __builtin_bit_cast(V4, (U4)__builtin_amdgcn_raw_buffer_load_b128(ro, goff[n], so, 0));
+        }
 #pragma unroll
-        for (int n = 0; n < NH; ++n) hx[n] = pg[hgo[n]];
+        for (int n = 0; n < NH; ++n) hx[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, hgo[n], so, 0));
     };
     fetch(hlo);
     auto step = [&](auto slot, const int hp) {
@@ -1428,7 +1454,7 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     sdot = fma((double)g[c], (double)of[n][c], sdot);
-                    if (of[n][c] == 1.0f) note.add(base + (int64_t)hp * P + goff[n] + c);
+                    if (of[n][c] == 1.0f) note.add(base + (int64_t)hp * P + (goff[n] >> 2) + c);
                 }
             }
         }
@@ -1515,7 +1541,7 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
                 }
                 acc += acc2;
             }
-            if (ok[n]) *reinterpret_cast<V4*>(db + (int64_t)hout * P + goff[n]) = acc;
+            if (ok[n]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, acc), rd, goff[n], hout * plane_bytes, 0);
         }
     };
 #define KCCOT_F3_STEP(S) if constexpr (S < NW) { if (hp0 + S < hhi) step(std::integral_constant<int, S>{}, hp0 + S); }
