@@ -1122,6 +1122,7 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
             constexpr int s = decltype(slot)::value;
             // ---- registers -> A (the previous plane's T stage finished in front of that plane's second barrier); items a
             // thread does not own go to a dummy slot behind the buffers: no branches
+            if (!(abl & 128)) {
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
                 *reinterpret_cast<V4*>(f3lds + (ok[n] ? boff[n] + R * pitch : dummy)) = x[n];
@@ -1132,6 +1133,7 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
                 f3lds[hao[n]] = hx[n];
                 f3lds[hmi[n]] = hx[n];
             }
+            }
             if (!(abl & 1)) {   // the next plane's piece, in flight across this plane's stencils
                 const int so = reflect(min(hp + 1, hhi - 1), a.H) * plane_bytes;
 #pragma unroll
@@ -1139,7 +1141,7 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
 #pragma unroll
                 for (int n = 0; n < F3_NH; ++n) hx[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, hgo[n], so, 0));
             }
-            lds_barrier();
+            if (!(abl & 512)) lds_barrier();
             // ---- T stencil: A -> B over the whole pitch (interior + column halo).  A thread takes a strip of LT rows of one float4
             // column: LT + 2R rows read once, LT outputs -- 2.5 LDS reads per output instead of 7 (the walk is bound by LDS
             // bandwidth before VALU issue: ~18 b128 accesses per output float4 against ~60 VALU instructions).  Same fma order.
@@ -1167,7 +1169,7 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
                     }
                 }
             }
-            lds_barrier();
+            if (!(abl & 512)) lds_barrier();
             // ---- W stencil: B -> the window's slot s
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
@@ -1188,7 +1190,7 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
                 win[n][s] = V4{r[0], r[1], r[2], r[3]};
             }
             const int hout = hp - R;
-            if (hout >= h0) {               // else the window is not full yet (uniform)
+            if (hout >= h0 && !(abl & 256)) {               // else the window is not full yet (uniform)
                 // ---- H stencil over the register window, emit plane hout
 #pragma unroll
                 for (int n = 0; n < NI; ++n) {
@@ -1939,7 +1941,7 @@ extern "C" int kccot_smooth_fwd_f32(const float* in, int B, int H, int T, int W,
             if (!ext) {
                 fa.mode = 0; fa.blockmax = bmax;
 #ifdef KCCOT_DIAG
-                if (const char* e = getenv("KCCOT_F3_ABLATE")) fa.mode |= (atoi(e) & 7) << 8;
+                if (const char* e = getenv("KCCOT_F3_ABLATE")) fa.mode |= (atoi(e) & (7 | 128 | 256 | 512)) << 8;
                 if (!(getenv("KCCOT_F3_ABLATE") && (atoi(getenv("KCCOT_F3_ABLATE")) & 64)))     // bit 6: writing pass only
 #endif
                 if ((rc = launch_fused3(fp, fa, radius, C, st))) return rc;
