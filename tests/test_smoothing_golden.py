@@ -450,3 +450,46 @@ def test_fused_3d_adjoint_equals_the_chain(shape, ties):
     assert bool(torch.isfinite(fused).all())
     assert float((fused - chain).abs().max()) <= 2e-6 * scale, (shape, ties)
     assert float((fused - legacy).abs().max()) <= 3e-6 * scale, (shape, ties)
+
+
+@pytest.mark.gpu
+def test_fused_3d_walks_on_random_shapes():
+    """The fused 3-D walks (forward: bit-identical to the chain; adjoint: to 2e-6 of max|din|) over forty random shapes: batch
+    sizes that leave the chip part-filled (H cut into segments whose last one is short), H and T that are not multiples of
+    anything, W that tiles into 1 / 2 / 4 column tiles, both channel counts, both radii forward (the adjoint is radius 3)."""
+    import torch
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, check, ptr
+    rng = np.random.default_rng(20261005)
+    axes = _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W
+    done = 0
+    while done < 40:
+        C = int(rng.choice([1, 3]))
+        W = int(rng.choice([8, 12, 16, 24, 32, 40, 64, 96, 128])) if C == 3 else int(rng.choice([8, 16, 32, 64, 128]))
+        T = int(rng.integers(10, 50))
+        H = int(rng.integers(8, 70))
+        B = int(rng.choice([1, 2, 3, 5, 8, 17]))
+        r = int(rng.choice([3, 3, 4]))
+        if (W * C) % 4 or B * H * T * W * C > 6_000_000:
+            continue
+        done += 1
+        shape = (B, H, T, W, C)
+        n = B * H * T * W * C
+        v = torch.from_numpy(rng.random(shape, dtype=np.float32)).cuda()
+        g = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda()
+        wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+        res = {}
+        for fused in (2, 0):
+            with _lib.options(smooth_fused3=fused, smooth_bwd_fold=2):
+                ws = torch.empty(wsb // 4 + 64, device="cuda")
+                out = torch.full(shape, float("nan"), device="cuda")
+                mx = torch.zeros(1, device="cuda")
+                check(lib.kccot_smooth_fwd_f32(ptr(v), B, H, T, W, C, 1.7, r, axes, ptr(out), ptr(mx), ws.data_ptr(), wsb, None), "fwd")
+                din = torch.full(shape, float("nan"), device="cuda")
+                check(lib.kccot_smooth_bwd_f32(ptr(g), ptr(out), ptr(mx), B, H, T, W, C, 1.7, r, axes, ptr(din), ws.data_ptr(), wsb, None), "bwd")
+                torch.cuda.synchronize()
+                res[fused] = (out, mx.clone(), din)
+        assert torch.equal(res[2][0], res[0][0]) and torch.equal(res[2][1], res[0][1]), shape + (r,)
+        scale = float(res[0][2].abs().max())
+        assert bool(torch.isfinite(res[2][2]).all()), shape + (r,)
+        assert float((res[2][2] - res[0][2]).abs().max()) <= 2e-6 * scale, shape + (r,)
