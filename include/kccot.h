@@ -106,8 +106,9 @@ const char* kccot_last_error(void);
  *   smooth_fused3             1        0: the 3-D smoothing as the chain of per-axis stages (five to seven tensor moves forward, seven
  *                                      backward); 1: T, W and H stage in ONE pass per call phase (three moves + halo; forward: same
  *                                      bits, backward: to rounding) where that was measured faster: forward three channels and
- *                                      >= 20 M elements (radius 3 / 4), backward >= 3.5 M elements (radius 3, statistics folded:
- *                                      smooth_bwd_fold != 0); 2: wherever it can run (C = 1 or 3; tests)
+ *                                      >= 20 M elements (radius 3 / 4), backward >= 3.5 M elements (radius 3; statistics folded:
+ *                                      smooth_bwd_fold != 0, or handed in: kccot_smooth_bwd_sharded_f32); 2: wherever it can run
+ *                                      (C = 1 or 3; tests)
  * ------------------------------------------------------------------------------------------- */
 int kccot_set_option(const char* name, int value);
 int kccot_get_option(const char* name, int* value);

@@ -1343,12 +1343,16 @@ struct Fused3AdjArgs {
     const float* out_fwd;
     float* din;
     const float* mx;
-    TieRec* ties;          // one record per workgroup
+    TieRec* ties;          // one record per workgroup (not XM)
+    const float* res;      // XM: {sum gout * out, #(out == 1)} over the whole batch
     int H, T, W, wt, ntw, hseg, nseg;
     Taps tp;
 };
 
-template <int R, int CC, int NI>
+// XM: the batch-sharded caller's form (KCCOT_SMOOTH_EXTERNAL_STATS): the two sums are known (all-reduced over the ranks), so the
+// normalisation's adjoint is applied while the planes are loaded, x = gout / max - corr [out == 1] -- for the halo columns too --
+// and nothing is gathered.
+template <int R, int CC, int NI, bool XM>
 __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
     typedef WalkVec<4>::type V4;
     extern __shared__ __attribute__((aligned(16))) float f3lds[];
@@ -1376,7 +1380,8 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
     rcp_m = fmaf(fmaf(-m, rcp_m, 1.f), rcp_m, rcp_m);
     const bool fast_div = fabsf(m) > 0x1p-40f && fabsf(m) < 0x1p40f;
     for (int i = tid; i < 2 * R * wtc; i += NT) { Bz[i] = 0.f; Bz[(T + 2 * R) * wtc + i] = 0.f; }
-    note.clear();
+    if (!XM) note.clear();
+    const float corr = XM ? (a.res[1] > 0.f ? a.res[0] / (m * a.res[1]) : 0.f) : 0.f;
 
     int goff[NI], ard[NI], brd[NI], bmir[NI];     // ard / brd: the item's position in A / Bz (writes of items a thread does not
                                                   // own are redirected to the dummy slot where they happen)
@@ -1429,7 +1434,7 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
         for (int n = 0; n < NH; ++n) hwin[n][j] = 0.f;
     }
     V4 x[NI], of[NI];
-    float hx[NH];
+    float hx[NH], hof[NH];
     double sdot = 0.0;
     const int hlo = h0 - R, hhi = h1 + R;
     auto fetch = [&](int hp) {
@@ -1441,7 +1446,10 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
             of[n] = __builtin_bit_cast(V4, (U4)__builtin_amdgcn_raw_buffer_load_b128(ro, goff[n], so, 0));
         }
 #pragma unroll
-        for (int n = 0; n < NH; ++n) hx[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, hgo[n], so, 0));
+        for (int n = 0; n < NH; ++n) {
+            hx[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, hgo[n], so, 0));
+            if (XM) hof[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro, hgo[n], so, 0));
+        }
     };
     fetch(hlo);
     auto step = [&](auto slot, const int hp) {
@@ -1451,8 +1459,13 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
             const V4 g = x[n];
-            win[n][s] = exists ? div_m(g) : V4{0.f, 0.f, 0.f, 0.f};
-            if (owned && ok[n]) {
+            V4 xs = div_m(g);
+            if (XM) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xs[c] = xs[c] - (of[n][c] == 1.0f ? corr : 0.f);
+            }
+            win[n][s] = exists ? xs : V4{0.f, 0.f, 0.f, 0.f};
+            if (!XM && owned && ok[n]) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     sdot = fma((double)g[c], (double)of[n][c], sdot);
@@ -1461,7 +1474,11 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
             }
         }
         {
-            const V4 q = div_m(V4{hx[0], hx[1], hx[2], 0.f});          // NH == 3
+            V4 q = div_m(V4{hx[0], hx[1], hx[2], 0.f});          // NH == 3
+            if (XM) {
+#pragma unroll
+                for (int n = 0; n < NH; ++n) q[n] = q[n] - (hof[n] == 1.0f ? corr : 0.f);
+            }
 #pragma unroll
             for (int n = 0; n < NH; ++n) hwin[n][s] = exists ? q[n] * hz[n] : 0.f;
         }
@@ -1552,13 +1569,14 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
         KCCOT_F3_STEP(5) KCCOT_F3_STEP(6) KCCOT_F3_STEP(7) KCCOT_F3_STEP(8)
     }
 #undef KCCOT_F3_STEP
-    note.store(a.ties + blockIdx.x, sdot);
+    if (!XM) note.store(a.ties + blockIdx.x, sdot);
 }
 
-static int launch_fused3_adj(const Fused3Plan& pl, Fused3AdjArgs fa, int C, hipStream_t st) {
-#define KCCOT_F3A(CCC, NN) hipLaunchKernelGGL((smooth_fused3_adj<3, CCC, NN>), dim3((unsigned)pl.grid), dim3(pl.nt), pl.lds, st, fa)
-#define KCCOT_F3A_N(CCC) switch (pl.ni) { case 1: KCCOT_F3A(CCC, 1); break; case 2: KCCOT_F3A(CCC, 2); break; default: KCCOT_F3A(CCC, 3); break; }
-    if (C == 1) { KCCOT_F3A_N(1) } else { KCCOT_F3A_N(3) }
+static int launch_fused3_adj(const Fused3Plan& pl, Fused3AdjArgs fa, int C, bool xm, hipStream_t st) {
+#define KCCOT_F3A(CCC, NN, XX) hipLaunchKernelGGL((smooth_fused3_adj<3, CCC, NN, XX>), dim3((unsigned)pl.grid), dim3(pl.nt), pl.lds, st, fa)
+#define KCCOT_F3A_N(CCC, XX) switch (pl.ni) { case 1: KCCOT_F3A(CCC, 1, XX); break; case 2: KCCOT_F3A(CCC, 2, XX); break; default: KCCOT_F3A(CCC, 3, XX); break; }
+    if (xm) { if (C == 1) { KCCOT_F3A_N(1, true) } else { KCCOT_F3A_N(3, true) } }
+    else { if (C == 1) { KCCOT_F3A_N(1, false) } else { KCCOT_F3A_N(3, false) } }
 #undef KCCOT_F3A_N
 #undef KCCOT_F3A
     return launch_status("smooth_fused3_adj");
@@ -2125,8 +2143,14 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
     // Round 4: with the three adjoint stages in ONE pass (smooth_fused3_adj, which gathers the sums itself) folding pays from
     // 3.5 M elements on for the 3-D call -- the plan decides.
     Fused3Plan fpa{};
-    if (chain && three && !stats_in && fold_opt != 0 && ((uintptr_t)out & 15) == 0) fpa = fused3_plan(B, H, T, W, C, radius, gout, din, true);
+    if (chain && three && (stats_in || fold_opt != 0) && ((uintptr_t)out & 15) == 0) fpa = fused3_plan(B, H, T, W, C, radius, gout, din, true);
     const bool fold = chain && !stats_in && (fold_opt == 2 || fpa.ok || (fold_opt == 1 && n >= (three ? (int64_t)1 << 25 : (int64_t)1 << 22)));
+    if (stats_in && fpa.ok) {       // the batch-sharded caller: sums handed in, correction applied at the loads, nothing to fix up
+        Fused3AdjArgs fa{};
+        fa.gout = gout; fa.out_fwd = out; fa.din = din; fa.mx = max_in; fa.res = stats_ext;
+        fa.H = H; fa.T = T; fa.W = W; fa.wt = fpa.wt; fa.ntw = W / fpa.wt; fa.hseg = fpa.hseg; fa.nseg = (H + fpa.hseg - 1) / fpa.hseg; fa.tp = tp;
+        return launch_fused3_adj(fpa, fa, C, true, st);
+    }
     if (stats_in) {
         res = stats_ext;                                       // the global sums: every kernel below reads res[0], res[1]
     } else if (!fold) {
@@ -2182,7 +2206,7 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
                     fa.gout = gout; fa.out_fwd = out; fa.din = din; fa.mx = max_in; fa.ties = recs;
                     fa.H = H; fa.T = T; fa.W = W; fa.wt = fp.wt; fa.ntw = W / fp.wt; fa.hseg = fp.hseg;
                     fa.nseg = (H + fp.hseg - 1) / fp.hseg; fa.tp = tp;
-                    if ((rc = launch_fused3_adj(fp, fa, C, st))) return rc;
+                    if ((rc = launch_fused3_adj(fp, fa, C, false, st))) return rc;
                     nrec = (int)fp.grid;
                     return finish();
                 }

@@ -493,3 +493,53 @@ def test_fused_3d_walks_on_random_shapes():
         scale = float(res[0][2].abs().max())
         assert bool(torch.isfinite(res[2][2]).all()), shape + (r,)
         assert float((res[2][2] - res[0][2]).abs().max()) <= 2e-6 * scale, shape + (r,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 40, 30, 64, 1), (2, 24, 30, 64, 3), (1, 20, 48, 128, 3)])
+@pytest.mark.parametrize("ties", ["none", "corners"])
+def test_fused_3d_adjoint_with_handed_in_sums(shape, ties):
+    """The batch-sharded backward (kccot_smooth_bwd_sharded_f32): phase 1 returns this rank's two sums, phase 2 takes the all-reduced
+    ones (KCCOT_SMOOTH_EXTERNAL_STATS).  With "smooth_fused3" phase 2 is the fused adjoint in its XM form -- the normalisation's
+    adjoint x = gout / max - corr [out == 1] applied at the loads, halo columns included, nothing gathered -- against the chain
+    (WALK_ADJX first stage): 2e-6 of max|din|; and against the one-call backward of the same tensor (world size 1: the handed-in sums
+    ARE the tensor's), whose correction goes the sparse way."""
+    import torch
+    from kccotgan_amd import _lib
+    from kccotgan_amd._lib import lib, check, ptr
+    B, H, T, W, C = shape
+    rng = np.random.default_rng(sum(shape) + len(ties))
+    n = int(np.prod(shape))
+    out = rng.random(shape, dtype=np.float32) * 0.98
+    if ties == "corners":
+        for idx in ((0, 0, 0, 0, 0), (B - 1, H - 1, T - 1, W - 1, C - 1), (0, 1, T - 2, 0, 0), (0, H - 1, 0, W - 1, 0), (0, 2, 3, 2, 0)):
+            out[idx] = 1.0
+    g = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda()
+    o = torch.from_numpy(out).cuda()
+    mx = torch.tensor([1.7], device="cuda")
+    axes = _lib.SMOOTH_T | _lib.SMOOTH_H | _lib.SMOOTH_W
+    wsb = int(lib.kccot_smooth_workspace_bytes(B, H, T, W, C))
+    ws = torch.empty(wsb // 4 + 64, device="cuda")
+    stats = torch.zeros(2, device="cuda")
+    dummy = torch.empty(shape, device="cuda")
+    check(lib.kccot_smooth_bwd_sharded_f32(ptr(g), ptr(o), ptr(mx), ptr(stats), B, H, T, W, C, 2.1, 3, axes | _lib.SMOOTH_STATS_ONLY,
+                                           ptr(dummy), ws.data_ptr(), wsb, None), "stats")
+    torch.cuda.synchronize()
+    assert int(stats[1]) == (5 if ties == "corners" else 0)
+    res = {}
+    for fused in (2, 0):
+        with _lib.options(smooth_fused3=fused):
+            din = torch.full(shape, float("nan"), device="cuda")
+            ws[:n] = -7.0
+            check(lib.kccot_smooth_bwd_sharded_f32(ptr(g), ptr(o), ptr(mx), ptr(stats), B, H, T, W, C, 2.1, 3,
+                                                   axes | _lib.SMOOTH_EXTERNAL_STATS, ptr(din), ws.data_ptr(), wsb, None), "bwd")
+            torch.cuda.synchronize()
+            assert bool((ws[:n] != -7.0).any()) == (fused == 0)      # the chain writes the intermediate buffer, the fused pass does not
+            res[fused] = din
+    with _lib.options(smooth_fused3=0, smooth_bwd_fold=0):
+        whole = torch.empty(shape, device="cuda")
+        check(lib.kccot_smooth_bwd_f32(ptr(g), ptr(o), ptr(mx), B, H, T, W, C, 2.1, 3, axes, ptr(whole), ws.data_ptr(), wsb, None), "bwd")
+        torch.cuda.synchronize()
+    scale = float(whole.abs().max())
+    assert float((res[2] - res[0]).abs().max()) <= 2e-6 * scale
+    assert float((res[2] - whole).abs().max()) <= 3e-6 * scale
