@@ -753,6 +753,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed replays in front of the W warm-up steps until the card has been busy for ~60 ms: W = 10 steps are 2 ms, not enough
+    # for the clocks to come back from the idle state the host-side capture leaves them in, and the timed window (K steps = 4-10 ms)
+    # is short enough for that ramp to show as +20 % in one run out of a few (profiles/r4ci6_bench.json: 0.227 ms in the window,
+    # 0.193 ms median of the per-step events right behind it, identical kernel durations).  Same step, nothing timed, bounded.
+    # (N > 1: the step holds collectives, so every rank must run the SAME number of them: a fixed count there)
+    settle = 0
+    t_settle = time.perf_counter()
+    while (settle < 400 and time.perf_counter() - t_settle < 0.06) if world == 1 else settle < 20:
+        for _ in range(10):
+            loss, _g = step()
+        torch.cuda.synchronize()
+        settle += 10
     for _ in range(args.warmup):
         loss, _g = step()
     barrier()
@@ -779,7 +791,7 @@ def main():
 
     out = {
         "metric": "sinkhorn_loss_evals_per_sec", "value": args.steps / el, "unit": "loss-evals/s (fwd+bwd)",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps_before_warmup": settle, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: Moving-MNIST shape B=64,T=30,64x64x1, J=8, 100 Sinkhorn iters, "
                                "compute_sinkhorn_loss fwd+bwd", "global_batch": SHAPE["B"],
