@@ -1200,7 +1200,8 @@ def test_fused_3d_smoothing_is_the_default_where_it_was_measured_faster(L):
         buf = torch.empty(wsb // 4 + 64, device=DEV)
         buf[:v.numel()] = -7.0
         out, mx = torch.empty_like(v), torch.zeros(1, device=DEV)
-        check(lib.kccot_smooth_fwd_f32(ptr(v), B, H, T, W, C, 2.0, 3, axes, ptr(out), ptr(mx), buf.data_ptr(), wsb, None), "smooth_fwd")
+        with L.options(smooth_fused3=1):        # (the default, also under a KCCOT_OPTIONS seed that forces the kernels on or off)
+            check(lib.kccot_smooth_fwd_f32(ptr(v), B, H, T, W, C, 2.0, 3, axes, ptr(out), ptr(mx), buf.data_ptr(), wsb, None), "smooth_fwd")
         torch.cuda.synchronize()
         assert bool((buf[:v.numel()] != -7.0).any()) == (not fused), shape
         assert float(out.max()) == 1.0
