@@ -1345,6 +1345,7 @@ struct Fused3AdjArgs {
     const float* mx;
     TieRec* ties;          // one record per workgroup (not XM)
     const float* res;      // XM: {sum gout * out, #(out == 1)} over the whole batch
+    const int* run_if;     // XM: non-null -> the launch does nothing unless *run_if != 0 (the dense fallback behind the fix-up)
     int H, T, W, wt, ntw, hseg, nseg;
     Taps tp;
 };
@@ -1375,6 +1376,7 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
     const auto ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.out_fwd + base), 0, 0xFFFFFFFFu, 0x00020000);
     const auto rd = __builtin_amdgcn_make_buffer_rsrc(a.din + base, 0, 0xFFFFFFFFu, 0x00020000);
     const int plane_bytes = (int)(P * 4);
+    if (XM && a.run_if && *a.run_if == 0) return;
     const float m = a.mx[0];
     float rcp_m = __builtin_amdgcn_rcpf(m);
     rcp_m = fmaf(fmaf(-m, rcp_m, 1.f), rcp_m, rcp_m);
@@ -2171,7 +2173,7 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
             int nrec = (int)((n / (three ? H : T) / p1.vw + 255) / 256);
             // what follows the last stage when the statistics were folded into the first: the sparse fix-up, then the
             // dense chain that only runs when the fix-up found too many arg-max elements
-            auto finish = [&]() -> int {
+            auto finish = [&](const Fused3Plan* fused = nullptr) -> int {
                 if (!fold) return 0;
                 int* dense = reinterpret_cast<int*>(scal + 7);
                 FixupArgs fa{};
@@ -2180,6 +2182,14 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
                 hipLaunchKernelGGL(maxnorm_bwd_fixup, dim3(1), dim3(1024), 0, st, fa);
                 int rc2 = launch_status("maxnorm_bwd_fixup");
                 if (rc2) return rc2;
+                if (fused) {    // dense fallback of the fused walk: the same walk once more, guarded, with the sums the fix-up has just
+                                // written and the correction applied at the loads (one guarded launch instead of three)
+                    Fused3AdjArgs fx{};
+                    fx.gout = gout; fx.out_fwd = out; fx.din = din; fx.mx = max_in; fx.res = res; fx.run_if = dense;
+                    fx.H = H; fx.T = T; fx.W = W; fx.wt = fused->wt; fx.ntw = W / fused->wt; fx.hseg = fused->hseg;
+                    fx.nseg = (H + fused->hseg - 1) / fused->hseg; fx.tp = tp;
+                    return launch_fused3_adj(*fused, fx, C, true, st);
+                }
                 // the round-2 chain with the sums the fix-up has just written: H^T (+ normalisation adjoint) gout -> din,
                 // W^T din -> tmp, T^T tmp -> din;  temporal only: T^T (+ normalisation adjoint) gout -> din
                 WalkArgs wd{};
@@ -2208,7 +2218,7 @@ static int smooth_bwd_impl(const float* gout, const float* out, const float* max
                     fa.nseg = (H + fp.hseg - 1) / fp.hseg; fa.tp = tp;
                     if ((rc = launch_fused3_adj(fp, fa, C, false, st))) return rc;
                     nrec = (int)fp.grid;
-                    return finish();
+                    return finish(&fp);
                 }
             }
             // H^T (+ normalisation adjoint): gout -> din;  W^T: din -> tmp;  T^T: tmp -> din
