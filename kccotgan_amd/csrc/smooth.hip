@@ -1032,7 +1032,10 @@ __global__ __launch_bounds__(512) void smooth_fused3(Fused3Args a) {
     // four floats behind B: the target of writes a thread has no item for (one slot for all: same-address LDS writes do not
     // serialise -- a slot per thread measured no faster and its 8 KB pushed the configs[2..3] tiles over the LDS budget)
     const int dummy = (2 * T + 2 * R) * pitch;
+    // workgroups are dealt to the eight XCDs round-robin: give each XCD a CONTIGUOUS run of tiles, so that the column tiles of a
+    // plane and the H segments of a sample -- which read each other's halo -- share an L2
     int blk = blockIdx.x;
+    if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
     const int tw = blk % a.ntw; blk /= a.ntw;
     const int seg = blk % a.nseg, b = blk / a.nseg;
     const int w0 = tw * a.wt, h0 = seg * a.hseg, h1 = min(h0 + a.hseg, a.H);
@@ -1364,7 +1367,10 @@ __global__ __launch_bounds__(512) void smooth_fused3_adj(Fused3AdjArgs a) {
     float* A = f3lds;                             // T x pitch: the H^T-smoothed plane piece with its column halo
     float* Bz = f3lds + T * pitch;                // (T + 4R) x wtc: W^T-smoothed, 2R zero rows above and below
     const int dummy = T * pitch + (T + 4 * R) * wtc;      // four floats behind: the target of writes a thread has no item for
+    // workgroups are dealt to the eight XCDs round-robin: give each XCD a CONTIGUOUS run of tiles, so that the column tiles of a
+    // plane and the H segments of a sample -- which read each other's halo -- share an L2
     int blk = blockIdx.x;
+    if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
     const int tw = blk % a.ntw; blk /= a.ntw;
     const int seg = blk % a.nseg, b = blk / a.nseg;
     const int w0 = tw * a.wt, h0 = seg * a.hseg, h1 = min(h0 + a.hseg, a.H);
