@@ -669,17 +669,19 @@ def test_graphed_loss_step_at_a_large_batch(G, L):
     assert not torch.equal(gl2.reshape(()), loss.detach().reshape(())) and bool(torch.isfinite(gl2))
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 9, 10, 2), (2, 9, 30, 64, 1), (2, 6, 20, 16, 3)])
-def test_smoothing_replays_as_a_graph(L, shape):
+@pytest.mark.parametrize("shape,fused", [((2, 8, 9, 10, 2), 1), ((2, 9, 30, 64, 1), 1), ((2, 6, 20, 16, 3), 1),
+                                         ((3, 20, 30, 64, 1), 2), ((2, 24, 30, 64, 3), 2)])
+def test_smoothing_replays_as_a_graph(L, shape, fused):
     """KernelSmoothing forward + backward (temporal and 3-D; the shapes take the LDS plane kernel with its memset scalars,
-    the lane-exchange walk, the any-channel kernels; statistics folded and not) captured and replayed three times."""
+    the lane-exchange walk, the any-channel kernels; statistics folded and not; fused = 2: the 3-D calls as the fused walks
+    of round 4, H cut into segments / three channels) captured and replayed three times."""
     from kccotgan_amd.data_utils import KernelSmoothing
     ks = KernelSmoothing(6, 6)
     gen = torch.Generator(device=DEV).manual_seed(sum(shape))
     x = torch.rand(shape, device=DEV, generator=gen)
     w = torch.randn(shape, device=DEV, generator=gen)
     for fold in (0, 2):
-        with L.options(smooth_bwd_fold=fold):
+        with L.options(smooth_bwd_fold=fold, smooth_fused3=fused):
             for fn in (ks.temporal_convolution, ks.gaussian_convolution3D):
                 def step():
                     xi = x.detach().requires_grad_(True)
