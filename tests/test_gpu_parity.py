@@ -1153,7 +1153,8 @@ def test_smoothing_stream_and_legacy_paths_agree(L):
                                          ((1, 20, 48, 128, 3), 6),     # configs[4]'s plane: three items per thread, four tiles
                                          ((2, 12, 12, 16, 1), 8),      # radius 4
                                          ((2, 11, 14, 24, 3), 8),      # radius 4, C = 3, odd H
-                                         ((70, 9, 8, 8, 1), 6)])       # T = 2 R + 2: every row but two is mirrored; one tile
+                                         ((70, 9, 8, 8, 1), 6),        # T = 2 R + 2: every row but two is mirrored; one tile
+                                         ((4200, 8, 8, 8, 1), 6)])     # > 4096 workgroups: the maxima are reduced by a launch of their own
 def test_fused_3d_smoothing_is_bit_identical_to_the_chain(L, shape, ksize):
     """Round 4: gaussian_convolution3D as ONE pass per phase (csrc/smooth.hip, smooth_fused3: T and W stencils through LDS, H
     stencil over a register window while the workgroup walks along H; maxima pass + writing pass = three tensor moves) against
